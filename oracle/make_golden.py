@@ -1,0 +1,354 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.json by RUNNING the reference's own, unmodified code.
+
+Test infrastructure.  Runs only in the build container (needs /root/reference);
+its outputs are committed, the reference never is.  Usage:
+
+    python oracle/make_golden.py            # rewrites tests/golden/ref_*.json
+
+How the reference is made importable offline:
+`src/search_engine.py` imports `voyageai` (not installed) and
+`processing.preprocess_bm25` (imports nltk and calls `nltk.download` at import).
+Two stub modules are planted in `sys.modules` before the import; nothing on the
+hot path touches them (`vo` is None, tokens arrive pre-processed).
+
+Vectors:
+  G1 dense   SearchEngine.similarity_search_with_embedding   (search_engine.py:57-98)
+  G2 wrrf    SearchEngine.weighted_reciprocal_rank_fusion    (search_engine.py:21-34)
+  G3 bm25sel SearchEngine._core_bm25_search on fixed scores  (search_engine.py:205-243)
+  G4 e2e     RetrievalEvaluationSystem.retrieve_documents    (query_rag_retrieval.py:149-411)
+             over a temp SQLite `chunks` DB (create_database.py:58-65 + `url`)
+             and a BM25 pickle (bm25_search.py:82-93) that holds the ORACLE's
+             BM25Okapi restatement (rank_bm25 is not installed): G4 therefore pins
+             the glue, the filters, the selection and the fusion -- not BM25 scores.
+  G5 metrics retrieval_eval.calculate_metrics                (retrieval_eval.py:90-116)
+"""
+from __future__ import annotations
+
+import json
+import os
+import pickle
+import sqlite3
+import sys
+import tempfile
+import types
+
+import numpy as np
+import pandas as pd
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF_SRC = "/root/reference/src"
+OUT = os.path.join(REPO, "tests", "golden")
+sys.path.insert(0, REPO)
+sys.dont_write_bytecode = True  # never leave .pyc behind in the read-only reference
+
+
+def _plant_stubs():
+    v = types.ModuleType("voyageai")
+
+    class Client:  # constructed at query_rag_retrieval.py:29; never called afterwards
+        def __init__(self, *a, **k):
+            pass
+
+    v.Client = Client
+    sys.modules["voyageai"] = v
+    p = types.ModuleType("processing")
+    p.__path__ = []
+    pp = types.ModuleType("processing.preprocess_bm25")
+
+    def preprocess_text(text, use_lemmatization=False):
+        raise RuntimeError("tokeniser stub: golden vectors use pre-tokenised queries only")
+
+    pp.preprocess_text = preprocess_text
+    sys.modules["processing"] = p
+    sys.modules["processing.preprocess_bm25"] = pp
+    sys.path.insert(0, REF_SRC)
+
+
+class Document:
+    """Stand-in for langchain's Document (bm25_search.py:70): the reference only
+    reads `.page_content` and `.metadata` from it."""
+
+    def __init__(self, page_content, metadata):
+        self.page_content = page_content
+        self.metadata = metadata
+
+
+# ----------------------------------------------------------------------------- inputs
+SOURCE_POOL = ["CG100", "CG61", "NG12", "NG148", "NG243", "QS15", "TA210", "PH38", "ng7", "cg3", "NGX1"]
+
+
+def synth_sources(n, seed):
+    rng = np.random.default_rng(seed)
+    return [SOURCE_POOL[i] for i in rng.integers(0, len(SOURCE_POOL), size=n)]
+
+
+def synth_dense(n, d, seed, normalise=True):
+    rng = np.random.default_rng(seed)
+    e = rng.standard_normal((n, d), dtype=np.float32)
+    if normalise:
+        e /= np.linalg.norm(e, axis=1, keepdims=True)
+    return e
+
+
+def synth_query(e, seed, row=None):
+    rng = np.random.default_rng(seed)
+    if row is None:
+        q = rng.standard_normal(e.shape[1], dtype=np.float32)
+    else:
+        q = e[row] + 0.05 * rng.standard_normal(e.shape[1], dtype=np.float32)
+    return (q / np.linalg.norm(q)).astype(np.float32)
+
+
+def make_df(e, sources):
+    return pd.DataFrame(
+        {
+            "id": [f"{s}_chunk{i}" for i, s in enumerate(sources)],
+            "document": [f"text {i}" for i in range(len(sources))],
+            "source": sources,
+            "embedding": list(e),
+            "url": [None] * len(sources),
+        }
+    )
+
+
+# ----------------------------------------------------------------------------- G1
+def g1_dense(se):
+    cases = []
+    spec = [
+        # n, d, seeds (corpus, query), query row or None
+        (64, 8, 11, 12, 3),
+        (64, 8, 11, 13, None),
+        (9609, 384, 1234, 4321, 777),
+    ]
+    for n, d, cs, qs, row in spec:
+        e = synth_dense(n, d, cs)
+        sources = synth_sources(n, cs + 1)
+        df = make_df(e, sources)
+        for qdtype in ("float32", "float64"):
+            q = synth_query(e, qs, row).astype(qdtype)
+            for k in (1, 10, 25, n + 5):
+                if n > 1000 and k > 25:
+                    continue
+                for flt in (None, "CG", "CG,NG", "cg, ng", "ZZ"):
+                    r = se.similarity_search_with_embedding(q, df, "m", k, flt)
+                    cases.append(
+                        dict(
+                            n=n, d=d, corpus_seed=cs, source_seed=cs + 1, query_seed=qs, query_row=row,
+                            qdtype=qdtype, k=k, filter=flt,
+                            rows=[int(i) for i in r.index] if len(r) else [],
+                            sims=[float(x) for x in r["similarity"]] if len(r) else [],
+                            sim_dtype=str(r["similarity"].dtype) if len(r) else None,
+                        )
+                    )
+    # duplicated rows -> exact score ties (order inside a tie group is unspecified)
+    e = synth_dense(32, 8, 21)
+    e[5] = e[1]; e[9] = e[1]; e[20] = e[1]
+    sources = synth_sources(32, 22)
+    df = make_df(e, sources)
+    q = e[1].copy()
+    for k in (2, 3, 10):
+        r = se.similarity_search_with_embedding(q, df, "m", k, None)
+        cases.append(dict(n=32, d=8, corpus_seed=21, source_seed=22, dup_of=1, dups=[5, 9, 20], k=k,
+                          filter=None, qdtype="float32", rows=[int(i) for i in r.index],
+                          sims=[float(x) for x in r["similarity"]], sim_dtype=str(r["similarity"].dtype)))
+    # reference behaviour for a 2-D (batched) query: flatten -> out-of-range iloc -> empty frame
+    r = se.similarity_search_with_embedding(np.stack([q, q]), df, "m", 3, None)
+    cases.append(dict(batched_query_returns_empty=bool(r.empty)))
+    return cases
+
+
+# ----------------------------------------------------------------------------- G2
+def g2_wrrf(se):
+    rng = np.random.default_rng(99)
+    cases = []
+    universe = [f"doc{i}" for i in range(40)]
+    for trial in range(6):
+        lists = []
+        names = ["voyage-3-large", "BM25", "text-embedding-3-large", "unlisted-model"][: 2 + trial % 3]
+        for name in names:
+            ln = int(rng.integers(1, 26))
+            lists.append(([universe[i] for i in rng.permutation(40)[:ln]], name))
+        weights = {"voyage-3-large": 5.0, "BM25": 1.0, "text-embedding-3-large": 2.0}
+        for k in (40, 50, 60, 60.0):
+            out = se.weighted_reciprocal_rank_fusion(lists, weights, k)
+            cases.append(dict(lists=[[l, n] for l, n in lists], weights=weights, k=k,
+                              fused=[[i, float(s)] for i, s in out]))
+    # engineered exact ties: same rank in equally weighted lists
+    lists = [(["a", "b", "c"], "m1"), (["b", "a", "d"], "m2"), (["e", "f"], "m3")]
+    weights = {"m1": 1.0, "m2": 1.0, "m3": 2.0}
+    out = se.weighted_reciprocal_rank_fusion(lists, weights, 40)
+    cases.append(dict(lists=[[l, n] for l, n in lists], weights=weights, k=40,
+                      fused=[[i, float(s)] for i, s in out]))
+    return cases
+
+
+# ----------------------------------------------------------------------------- G3
+class FixedScores:
+    def __init__(self, scores):
+        self.scores = scores
+
+    def get_scores(self, tokens):
+        return self.scores
+
+
+def g3_bm25_selection(se):
+    rng = np.random.default_rng(5)
+    cases = []
+    for n, nz in ((40, 12), (40, 40), (300, 30)):
+        scores = np.zeros(n)
+        hit = rng.permutation(n)[:nz]
+        scores[hit] = np.round(rng.random(nz) * 8, 1)  # rounding makes equal non-zero scores likely
+        if n == 300:
+            scores[rng.permutation(n)[:5]] = -0.25  # negative idf contributions exist (epsilon floor)
+        sources = synth_sources(n, 6 + n)
+        sections = [Document(f"t{i}", {"id": f"sec{i}", "source": sources[i]}) for i in range(n)]
+        ids = [f"sec{i}" for i in range(n)]
+        for k in (1, 10, 25, n, n + 3):
+            for flt in (None, "CG", "CG,NG", "ZZ"):
+                out = se._core_bm25_search(["tok"], FixedScores(scores), sections, ids, k, flt)
+                cases.append(dict(scores=[float(x) for x in scores], sources=sources, k=k, filter=flt,
+                                  ids=list(out)))
+    out = se._core_bm25_search([], FixedScores(np.zeros(3)), [], [], 5, None)
+    cases.append(dict(empty_tokens=list(out)))
+    return cases
+
+
+# ----------------------------------------------------------------------------- G4
+VOCAB = ["asthma", "inhaler", "dose", "child", "adult", "review", "diabetes", "insulin", "renal",
+         "stroke", "therapy", "risk", "assessment", "offer", "consider", "referral", "urgent", "cancer",
+         "pain", "opioid", "pregnancy", "antenatal", "screening", "hypertension", "statin", "kidney",
+         "infection", "antibiotic", "sepsis", "fever"]
+
+
+def synth_chunks(n, seed):
+    rng = np.random.default_rng(seed)
+    p = 1.0 / np.arange(1, len(VOCAB) + 1) ** 1.07
+    p /= p.sum()
+    chunks = []
+    sources = synth_sources(n, seed + 1)
+    for i in range(n):
+        ln = 0 if i % 37 == 5 else int(rng.integers(3, 30))  # a few empty-token chunks (bm25_search.py:67-68)
+        toks = [VOCAB[j] for j in rng.choice(len(VOCAB), size=ln, p=p)]
+        chunks.append(dict(id=f"{sources[i]}_sec{i}", source=sources[i], content=" ".join(toks) or "-", tokens=toks))
+    return chunks
+
+
+def g4_end_to_end():
+    from oracle.ref_bm25 import BM25Okapi
+
+    n, d = 200, 16
+    chunks = synth_chunks(n, 300)
+    e1 = synth_dense(n, d, 301)
+    e2 = synth_dense(n, d, 302)
+    tmp = tempfile.mkdtemp(prefix="anrag_golden_")
+
+    def write_db(path, e):
+        conn = sqlite3.connect(path)
+        conn.execute("CREATE TABLE chunks (id TEXT PRIMARY KEY, content TEXT NOT NULL, source TEXT NOT NULL,"
+                     " embedding BLOB NOT NULL, created_at TIMESTAMP DEFAULT CURRENT_TIMESTAMP, url TEXT)")
+        for c, v in zip(chunks, e):
+            conn.execute("INSERT INTO chunks (id, content, source, embedding, url) VALUES (?,?,?,?,?)",
+                         (c["id"], c["content"], c["source"], np.asarray(v, np.float32).tobytes(), None))
+        conn.commit()
+        conn.close()
+
+    db1, db2 = os.path.join(tmp, "m1.db"), os.path.join(tmp, "m2.db")
+    write_db(db1, e1)
+    write_db(db2, e2)
+    # bm25_search.py:45-79: skip chunks whose token list is empty
+    kept = [c for c in chunks if c["tokens"]]
+    bm25 = BM25Okapi([c["tokens"] for c in kept], k1=1.7, b=0.83, epsilon=0.05)
+    sections = [Document(c["content"], {"id": c["id"], "source": c["source"]}) for c in kept]
+    pkl = os.path.join(tmp, "bm25.pkl")
+    with open(pkl, "wb") as f:
+        pickle.dump({"bm25": bm25, "sections": sections, "section_ids": [c["id"] for c in kept], "config": {}}, f)
+
+    import config as ref_config
+
+    sc = ref_config.Config.SOURCE_CONFIGS[ref_config.InfoSource.NICE]
+    sc.db_path = sc.voyage_db_path = db1
+    sc.openai_db_path = db2
+    sc.voyage_3_5_db_path = None
+    sc.qwen_db_path = None
+    sc.bm25_path = pkl
+    import query_rag_retrieval as qrr
+
+    system = qrr.RetrievalEvaluationSystem()
+    assert system.bm25_data[ref_config.InfoSource.NICE] is not None
+
+    rng = np.random.default_rng(303)
+    cases = []
+    for qi in range(12):
+        target = int(rng.integers(0, n))
+        q1 = synth_query(e1, 400 + qi, target)
+        q2 = synth_query(e2, 500 + qi, target)
+        toks = list(rng.choice(chunks[target]["tokens"] or VOCAB, size=int(rng.integers(1, 7))))
+        if qi % 4 == 1:
+            toks.append(toks[0])  # duplicated query token (counted twice by get_scores)
+        if qi % 4 == 2:
+            toks.insert(1, "notinvocab")
+        toks = [str(t) for t in toks]
+        for cfg in (
+            dict(similarity_k=25, common_sections_n=15, use_hybrid_search=False, wrrf_k=60,
+                 model_weights={"voyage-3-large": 5.0, "BM25": 1.0}, filename_type_filter=None),
+            dict(similarity_k=25, common_sections_n=15, use_hybrid_search=True, wrrf_k=40,
+                 model_weights={"voyage-3-large": 5.0, "BM25": 1.0}, filename_type_filter=None),
+            dict(similarity_k=25, common_sections_n=10, use_hybrid_search=True, wrrf_k=40,
+                 model_weights={"voyage-3-large": 5.0, "BM25": 1.0}, filename_type_filter="CG,NG"),
+            dict(similarity_k=10, common_sections_n=10, use_hybrid_search=True, wrrf_k=40,
+                 model_weights={"voyage-3-large": 0.0, "BM25": 1.0}, filename_type_filter="CG,NG"),
+            dict(similarity_k=25, common_sections_n=15, use_hybrid_search=True, wrrf_k=60,
+                 model_weights={"voyage-3-large": 2.0, "text-embedding-3-large": 1.0, "BM25": 1.0},
+                 filename_type_filter="NG"),
+            dict(similarity_k=300, common_sections_n=300, use_hybrid_search=True, wrrf_k=40,
+                 model_weights={"voyage-3-large": 5.0, "BM25": 1.0}, filename_type_filter="CG,NG"),
+        ):
+            out = system.retrieve_documents(
+                query_embeddings={"voyage-3-large": q1, "text-embedding-3-large": q2},
+                query_tokens=toks, use_reranker=False, **cfg,
+            )
+            cases.append(dict(target=target, q1_seed=400 + qi, q2_seed=500 + qi, tokens=toks, cfg=cfg, ids=list(out)))
+    corpus = dict(n=n, d=d, chunk_seed=300, e1_seed=301, e2_seed=302,
+                  chunks=[dict(id=c["id"], source=c["source"], tokens=c["tokens"]) for c in chunks])
+    return dict(corpus=corpus, cases=cases)
+
+
+# ----------------------------------------------------------------------------- G5
+def g5_metrics():
+    import retrieval_eval
+
+    sets = [
+        [dict(rank=1, found=True), dict(rank=3, found=True), dict(rank=-1, found=False), dict(rank=12, found=True)],
+        [dict(rank=-1, found=False)],
+        [dict(rank=r, found=True) for r in (1, 1, 2, 5, 6, 10, 11, 15, 16, 251)],
+        [],
+    ]
+    out = []
+    for s in sets:
+        m = retrieval_eval.calculate_metrics(s)
+        out.append(dict(results=s, metrics={k: (None if v is None else float(v)) for k, v in m.items()}))
+    return out
+
+
+def main():
+    _plant_stubs()
+    import search_engine
+
+    se = search_engine.SearchEngine(None, None)
+    os.makedirs(OUT, exist_ok=True)
+    blobs = {
+        "ref_dense.json": g1_dense(se),
+        "ref_wrrf.json": g2_wrrf(se),
+        "ref_bm25_selection.json": g3_bm25_selection(se),
+        "ref_end_to_end.json": g4_end_to_end(),
+        "ref_metrics.json": g5_metrics(),
+    }
+    for name, data in blobs.items():
+        with open(os.path.join(OUT, name), "w") as f:
+            json.dump(data, f, separators=(",", ":"))
+        print(name, os.path.getsize(os.path.join(OUT, name)), "bytes")
+
+
+if __name__ == "__main__":
+    main()
