@@ -1,0 +1,449 @@
+// C ABI of libanrag.so (include/anrag.h): index lifetime, uploads, query entry points.
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+
+#include "common.hpp"
+
+namespace anrag {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+// ------------------------------------------------------------------ profiling
+static hipEvent_t take_event(anrag_index *idx) {
+    if (!idx->event_pool.empty()) {
+        hipEvent_t e = idx->event_pool.back();
+        idx->event_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+}
+
+LaunchTimer::LaunchTimer(anrag_index *i, int k, hipStream_t s) : idx(i), stream(s), kernel(k) {
+    if (!idx->profiling) return;
+    start = take_event(idx);
+    stop = take_event(idx);
+    if (start) (void)hipEventRecord(start, stream);
+}
+
+LaunchTimer::~LaunchTimer() {
+    if (!idx->profiling || !start || !stop) return;
+    (void)hipEventRecord(stop, stream);
+    idx->spans.push_back(ProfSpan{kernel, start, stop});
+}
+
+int drain_profile(anrag_index *idx) {
+    for (ProfSpan &sp : idx->spans) {
+        ANRAG_HIP(hipEventSynchronize(sp.stop));
+        float ms = 0.f;
+        ANRAG_HIP(hipEventElapsedTime(&ms, sp.start, sp.stop));
+        idx->prof_ms[sp.kernel] += ms;
+        idx->prof_launches[sp.kernel] += 1;
+        idx->event_pool.push_back(sp.start);
+        idx->event_pool.push_back(sp.stop);
+    }
+    idx->spans.clear();
+    return ANRAG_OK;
+}
+
+// ------------------------------------------------------------------ small helpers
+template <typename T>
+static int dev_alloc(anrag_index *idx, T **p, int64_t count) {
+    *p = nullptr;
+    if (count <= 0) return ANRAG_OK;
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(p), (size_t)count * sizeof(T));
+    if (e != hipSuccess) {
+        set_error("hipMalloc(%lld bytes) failed: %s", (long long)(count * (int64_t)sizeof(T)), hipGetErrorString(e));
+        return ANRAG_ERR_NOMEM;
+    }
+    idx->hbm_bytes += count * (int64_t)sizeof(T);
+    return ANRAG_OK;
+}
+
+template <typename T>
+static void dev_free(anrag_index *idx, T *&p, int64_t count) {
+    if (p) {
+        (void)hipFree(p);
+        idx->hbm_bytes -= count * (int64_t)sizeof(T);
+        p = nullptr;
+    }
+}
+
+static int ensure_common_workspace(anrag_index *idx) {
+    int rc;
+    if (!idx->d_allow_a) {
+        if ((rc = dev_alloc(idx, &idx->d_allow_a, 2048))) return rc;
+        if ((rc = dev_alloc(idx, &idx->d_allow_b, 2048))) return rc;
+        if ((rc = dev_alloc(idx, &idx->d_terms, 4096))) return rc;
+    }
+    if (!idx->d_cand_a) {
+        idx->cand_cap = 4096;  // records per buffer (n_queries * k per call is chunked to this)
+        if ((rc = dev_alloc(idx, &idx->d_cand_a, idx->cand_cap))) return rc;
+        if ((rc = dev_alloc(idx, &idx->d_cand_b, idx->cand_cap))) return rc;
+        if ((rc = dev_alloc(idx, &idx->d_cand_out, idx->cand_cap))) return rc;
+    }
+    if (!idx->h_pinned) {
+        idx->pinned_bytes = 1 << 20;
+        ANRAG_HIP(hipHostMalloc(&idx->h_pinned, idx->pinned_bytes, hipHostMallocDefault));
+    }
+    return ANRAG_OK;
+}
+
+static int ensure_query_buffer(anrag_index *idx, int64_t floats) {
+    if (idx->query_cap >= floats) return ANRAG_OK;
+    dev_free(idx, idx->d_query, idx->query_cap);
+    idx->query_cap = 0;
+    int rc = dev_alloc(idx, &idx->d_query, floats);
+    if (rc) return rc;
+    idx->query_cap = floats;
+    return ANRAG_OK;
+}
+
+// bytes-per-source allow list (host) -> 2048-word bitmap staged in HBM; NULL allow -> nullptr (no filter)
+static int stage_allow(anrag_index *idx, hipStream_t st, const uint8_t *allow, int32_t n_sources, uint32_t *d_bits,
+                       uint32_t *h_bits, const uint32_t **out) {
+    *out = nullptr;
+    if (!allow) return ANRAG_OK;
+    ANRAG_REQUIRE(n_sources >= 0 && n_sources <= 65536, "n_sources %d out of range [0, 65536]", n_sources);
+    memset(h_bits, 0, 2048 * sizeof(uint32_t));
+    for (int32_t s = 0; s < n_sources; ++s)
+        if (allow[s]) h_bits[s >> 5] |= 1u << (s & 31);
+    ANRAG_HIP(hipMemcpyAsync(d_bits, h_bits, 2048 * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    *out = d_bits;
+    return ANRAG_OK;
+}
+
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = true;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) ok = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+#define ANRAG_ENTER(idx)                                                   \
+    ANRAG_REQUIRE((idx) != nullptr, "index handle is NULL");              \
+    std::lock_guard<std::mutex> lock__((idx)->mu);                        \
+    ::anrag::DeviceGuard guard__((idx)->device);                          \
+    if (!guard__.ok) {                                                    \
+        ::anrag::set_error("hipSetDevice(%d) failed", (idx)->device);     \
+        return ANRAG_ERR_HIP;                                             \
+    }
+
+}  // namespace anrag
+
+using namespace anrag;
+
+extern "C" {
+
+int anrag_abi_version(void) { return ANRAG_ABI_VERSION; }
+
+const char *anrag_last_error(void) { return g_err; }
+
+int anrag_device_count(int *out_count) {
+    ANRAG_REQUIRE(out_count != nullptr, "out_count is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        *out_count = 0;
+        set_error("hipGetDeviceCount failed: %s", hipGetErrorString(e));
+        return ANRAG_ERR_NODEVICE;
+    }
+    *out_count = n;
+    return ANRAG_OK;
+}
+
+int anrag_index_create(int device, anrag_index **out) {
+    ANRAG_REQUIRE(out != nullptr, "out is NULL");
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        set_error("no HIP device visible: libanrag has no CPU fallback");
+        return ANRAG_ERR_NODEVICE;
+    }
+    ANRAG_REQUIRE(device >= 0 && device < n, "device %d out of range (%d visible)", device, n);
+    hipDeviceProp_t prop;
+    ANRAG_HIP(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        set_error("device %d is %s; libanrag carries gfx950 code objects only", device, prop.gcnArchName);
+        return ANRAG_ERR_NODEVICE;
+    }
+    anrag_index *idx = new (std::nothrow) anrag_index();
+    if (!idx) {
+        set_error("out of host memory");
+        return ANRAG_ERR_NOMEM;
+    }
+    idx->device = device;
+    idx->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    DeviceGuard g(device);
+    hipError_t e = hipStreamCreateWithFlags(&idx->own_primary, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&idx->own_secondary, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&idx->ev_fork, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&idx->ev_join, hipEventDisableTiming);
+    if (e != hipSuccess) {
+        set_error("stream/event creation failed: %s", hipGetErrorString(e));
+        delete idx;
+        return ANRAG_ERR_HIP;
+    }
+    idx->primary = idx->own_primary;
+    idx->secondary = idx->own_secondary;
+    *out = idx;
+    return ANRAG_OK;
+}
+
+static void free_dense(anrag_index *idx) {
+    dev_free(idx, idx->d_emb, idx->n_rows * idx->dim);
+    dev_free(idx, idx->d_dense_src, idx->n_rows);
+    dev_free(idx, idx->d_dense_doc, idx->n_rows);
+    dev_free(idx, idx->d_scores_f32, idx->n_rows);
+    idx->n_rows = 0;
+    idx->dim = 0;
+}
+
+int anrag_index_destroy(anrag_index *idx) {
+    if (!idx) return ANRAG_OK;
+    {
+        DeviceGuard g(idx->device);
+        (void)hipStreamSynchronize(idx->primary);
+        (void)hipStreamSynchronize(idx->secondary);
+        (void)drain_profile(idx);
+        free_dense(idx);
+        free_bm25(idx);
+        void *ptrs[] = {idx->d_blk_score_f32, idx->d_blk_row_a, idx->d_blk_score_f64, idx->d_blk_row_b, idx->d_query,
+                        idx->d_allow_a,       idx->d_allow_b,   idx->d_terms,         idx->d_cand_a,    idx->d_cand_b,
+                        idx->d_cand_out,      idx->d_scores_f64, idx->d_sort_tmp,     idx->d_sort_buf};
+        for (void *p : ptrs)
+            if (p) (void)hipFree(p);
+        if (idx->h_pinned) (void)hipHostFree(idx->h_pinned);
+        for (hipEvent_t e : idx->event_pool) (void)hipEventDestroy(e);
+        if (idx->ev_fork) (void)hipEventDestroy(idx->ev_fork);
+        if (idx->ev_join) (void)hipEventDestroy(idx->ev_join);
+        if (idx->own_primary) (void)hipStreamDestroy(idx->own_primary);
+        if (idx->own_secondary) (void)hipStreamDestroy(idx->own_secondary);
+    }
+    delete idx;
+    return ANRAG_OK;
+}
+
+int anrag_index_set_streams(anrag_index *idx, void *primary, void *secondary) {
+    ANRAG_ENTER(idx);
+    ANRAG_HIP(hipStreamSynchronize(idx->primary));
+    ANRAG_HIP(hipStreamSynchronize(idx->secondary));
+    idx->primary = primary ? (hipStream_t)primary : idx->own_primary;
+    idx->secondary = secondary ? (hipStream_t)secondary : idx->own_secondary;
+    return ANRAG_OK;
+}
+
+int anrag_index_sync(anrag_index *idx) {
+    ANRAG_ENTER(idx);
+    ANRAG_HIP(hipStreamSynchronize(idx->primary));
+    ANRAG_HIP(hipStreamSynchronize(idx->secondary));
+    return ANRAG_OK;
+}
+
+// ------------------------------------------------------------------ dense
+int anrag_dense_load(anrag_index *idx, const float *embeddings, int64_t n_rows, int32_t dim,
+                     const uint16_t *source_id, const int64_t *doc_id, int64_t doc_id_base) {
+    ANRAG_ENTER(idx);
+    ANRAG_REQUIRE(embeddings != nullptr, "embeddings is NULL");
+    ANRAG_REQUIRE(n_rows > 0 && n_rows < 0xFFFFFFFFll, "n_rows %lld out of range (1 .. 2^32-2 per shard)",
+                  (long long)n_rows);
+    ANRAG_REQUIRE(dim > 0 && dim <= 65536, "dim %d out of range", dim);
+    ANRAG_HIP(hipStreamSynchronize(idx->primary));
+    free_dense(idx);
+    int rc;
+    if ((rc = ensure_common_workspace(idx))) return rc;
+    if ((rc = dev_alloc(idx, &idx->d_emb, n_rows * dim))) return rc;
+    idx->n_rows = n_rows;
+    idx->dim = dim;
+    ANRAG_HIP(hipMemcpy(idx->d_emb, embeddings, (size_t)n_rows * dim * sizeof(float), hipMemcpyDefault));
+    if (source_id) {
+        if ((rc = dev_alloc(idx, &idx->d_dense_src, n_rows))) return rc;
+        ANRAG_HIP(hipMemcpy(idx->d_dense_src, source_id, (size_t)n_rows * sizeof(uint16_t), hipMemcpyDefault));
+    }
+    if (doc_id) {
+        if ((rc = dev_alloc(idx, &idx->d_dense_doc, n_rows))) return rc;
+        ANRAG_HIP(hipMemcpy(idx->d_dense_doc, doc_id, (size_t)n_rows * sizeof(int64_t), hipMemcpyDefault));
+    }
+    idx->dense_doc_base = doc_id_base;
+    if (!idx->d_blk_score_f32) {
+        if ((rc = dev_alloc(idx, &idx->d_blk_score_f32, (int64_t)kMaxScanBlocks * kListLen))) return rc;
+        if ((rc = dev_alloc(idx, &idx->d_blk_row_a, (int64_t)kMaxScanBlocks * kListLen))) return rc;
+    }
+    if ((rc = ensure_query_buffer(idx, (int64_t)64 * dim))) return rc;
+    return ANRAG_OK;
+}
+
+int anrag_dense_search_device(anrag_index *idx, const float *d_queries, int32_t n_queries, int32_t k,
+                              const uint32_t *d_allow_bits, anrag_candidate *d_out) {
+    ANRAG_ENTER(idx);
+    ANRAG_REQUIRE(idx->d_emb != nullptr, "dense search before anrag_dense_load");
+    ANRAG_REQUIRE(d_queries && d_out, "NULL operand");
+    ANRAG_REQUIRE(n_queries > 0, "n_queries must be positive");
+    ANRAG_REQUIRE(k > 0 && k <= ANRAG_FUSED_K_MAX, "device path serves 1 <= k <= %d (got %d)", ANRAG_FUSED_K_MAX, k);
+    for (int32_t qi = 0; qi < n_queries; ++qi) {
+        int rc = launch_dense_topk(idx, idx->primary, d_queries + (int64_t)qi * idx->dim, k, d_allow_bits,
+                                   d_out + (int64_t)qi * k, nullptr);
+        if (rc) return rc;
+    }
+    return ANRAG_OK;
+}
+
+int anrag_dense_scores(anrag_index *idx, const float *query, float *out_scores) {
+    ANRAG_ENTER(idx);
+    ANRAG_REQUIRE(idx->d_emb != nullptr, "dense scores before anrag_dense_load");
+    ANRAG_REQUIRE(query && out_scores, "NULL operand");
+    int rc;
+    if (!idx->d_scores_f32 && (rc = dev_alloc(idx, &idx->d_scores_f32, idx->n_rows))) return rc;
+    hipStream_t st = idx->primary;
+    ANRAG_HIP(hipMemcpyAsync(idx->d_query, query, (size_t)idx->dim * sizeof(float), hipMemcpyHostToDevice, st));
+    if ((rc = launch_dense_topk(idx, st, idx->d_query, 0, nullptr, nullptr, idx->d_scores_f32))) return rc;
+    ANRAG_HIP(hipMemcpyAsync(out_scores, idx->d_scores_f32, (size_t)idx->n_rows * sizeof(float),
+                             hipMemcpyDeviceToHost, st));
+    ANRAG_HIP(hipStreamSynchronize(st));
+    return ANRAG_OK;
+}
+
+int anrag_dense_search(anrag_index *idx, const float *queries, int32_t n_queries, int32_t k,
+                       const uint8_t *allow_source, int32_t n_sources, int64_t *out_doc, float *out_score,
+                       int32_t *out_count) {
+    ANRAG_ENTER(idx);
+    ANRAG_REQUIRE(idx->d_emb != nullptr, "dense search before anrag_dense_load");
+    ANRAG_REQUIRE(queries && out_doc && out_score && out_count, "NULL operand");
+    ANRAG_REQUIRE(n_queries > 0 && k > 0, "n_queries and k must be positive");
+    hipStream_t st = idx->primary;
+    int rc;
+    const uint32_t *d_allow = nullptr;
+    uint32_t *h_bits = reinterpret_cast<uint32_t *>(idx->h_pinned);
+    if ((rc = stage_allow(idx, st, allow_source, n_sources, idx->d_allow_a, h_bits, &d_allow))) return rc;
+    ANRAG_REQUIRE(!(allow_source && !idx->d_dense_src), "a source filter needs source ids (anrag_dense_load)");
+    if (k > ANRAG_FUSED_K_MAX) {
+        return dense_search_large_k(idx, st, queries, n_queries, k, d_allow, out_doc, out_score, out_count);
+    }
+    anrag_candidate *h_cand = reinterpret_cast<anrag_candidate *>(static_cast<char *>(idx->h_pinned) + 8192);
+    const int32_t chunk = (int32_t)std::min<int64_t>(64, idx->cand_cap / k);
+    for (int32_t q0 = 0; q0 < n_queries; q0 += chunk) {
+        const int32_t nq = std::min(chunk, n_queries - q0);
+        ANRAG_HIP(hipMemcpyAsync(idx->d_query, queries + (int64_t)q0 * idx->dim, (size_t)nq * idx->dim * sizeof(float),
+                                 hipMemcpyHostToDevice, st));
+        for (int32_t qi = 0; qi < nq; ++qi)
+            if ((rc = launch_dense_topk(idx, st, idx->d_query + (int64_t)qi * idx->dim, k, d_allow,
+                                        idx->d_cand_out + (int64_t)qi * k, nullptr)))
+                return rc;
+        ANRAG_HIP(hipMemcpyAsync(h_cand, idx->d_cand_out, (size_t)nq * k * sizeof(anrag_candidate),
+                                 hipMemcpyDeviceToHost, st));
+        ANRAG_HIP(hipStreamSynchronize(st));
+        for (int32_t qi = 0; qi < nq; ++qi) {
+            int32_t cnt = 0;
+            for (int32_t i = 0; i < k; ++i) {
+                const anrag_candidate &c = h_cand[(int64_t)qi * k + i];
+                out_doc[(int64_t)(q0 + qi) * k + i] = c.doc;
+                out_score[(int64_t)(q0 + qi) * k + i] = (float)c.score;
+                if (c.doc >= 0) ++cnt;
+            }
+            out_count[q0 + qi] = cnt;
+        }
+    }
+    return ANRAG_OK;
+}
+
+// ------------------------------------------------------------------ sharded merge
+int anrag_merge_candidates_device(anrag_index *idx, const anrag_candidate *d_lists, int32_t n_lists, int32_t k,
+                                  anrag_candidate *d_out) {
+    ANRAG_ENTER(idx);
+    ANRAG_REQUIRE(d_lists && d_out, "NULL operand");
+    ANRAG_REQUIRE(n_lists > 0 && k > 0 && k <= ANRAG_FUSED_K_MAX, "need n_lists > 0 and 1 <= k <= %d",
+                  ANRAG_FUSED_K_MAX);
+    return launch_merge_candidates(idx, idx->primary, d_lists, n_lists, k, d_out);
+}
+
+// ------------------------------------------------------------------ device memory helpers
+int anrag_device_alloc(anrag_index *idx, int64_t bytes, void **out_ptr) {
+    ANRAG_ENTER(idx);
+    ANRAG_REQUIRE(out_ptr && bytes > 0, "bad arguments");
+    ANRAG_HIP(hipMalloc(out_ptr, (size_t)bytes));
+    return ANRAG_OK;
+}
+
+int anrag_device_free(anrag_index *idx, void *ptr) {
+    ANRAG_ENTER(idx);
+    if (ptr) ANRAG_HIP(hipFree(ptr));
+    return ANRAG_OK;
+}
+
+int anrag_copy_to_device(anrag_index *idx, void *d_dst, const void *h_src, int64_t bytes) {
+    ANRAG_ENTER(idx);
+    ANRAG_REQUIRE(d_dst && h_src && bytes >= 0, "bad arguments");
+    ANRAG_HIP(hipMemcpyAsync(d_dst, h_src, (size_t)bytes, hipMemcpyHostToDevice, idx->primary));
+    ANRAG_HIP(hipStreamSynchronize(idx->primary));
+    return ANRAG_OK;
+}
+
+int anrag_copy_to_host(anrag_index *idx, void *h_dst, const void *d_src, int64_t bytes) {
+    ANRAG_ENTER(idx);
+    ANRAG_REQUIRE(h_dst && d_src && bytes >= 0, "bad arguments");
+    ANRAG_HIP(hipMemcpyAsync(h_dst, d_src, (size_t)bytes, hipMemcpyDeviceToHost, idx->primary));
+    ANRAG_HIP(hipStreamSynchronize(idx->primary));
+    return ANRAG_OK;
+}
+
+// ------------------------------------------------------------------ measurement
+int anrag_profile_enable(anrag_index *idx, int on) {
+    ANRAG_ENTER(idx);
+    if (!on) {
+        int rc = drain_profile(idx);
+        if (rc) return rc;
+    }
+    idx->profiling = on != 0;
+    return ANRAG_OK;
+}
+
+int anrag_profile_reset(anrag_index *idx) {
+    ANRAG_ENTER(idx);
+    int rc = drain_profile(idx);
+    if (rc) return rc;
+    for (int i = 0; i < ANRAG_KERNEL_COUNT; ++i) {
+        idx->prof_ms[i] = 0;
+        idx->prof_launches[i] = 0;
+    }
+    return ANRAG_OK;
+}
+
+int anrag_profile_read(anrag_index *idx, int kernel_id, double *out_total_ms, int64_t *out_launches) {
+    ANRAG_ENTER(idx);
+    ANRAG_REQUIRE(kernel_id >= 0 && kernel_id < ANRAG_KERNEL_COUNT, "kernel id %d out of range", kernel_id);
+    ANRAG_REQUIRE(out_total_ms && out_launches, "NULL operand");
+    int rc = drain_profile(idx);
+    if (rc) return rc;
+    *out_total_ms = idx->prof_ms[kernel_id];
+    *out_launches = idx->prof_launches[kernel_id];
+    return ANRAG_OK;
+}
+
+int anrag_index_info(anrag_index *idx, int64_t *dense_rows, int32_t *dense_dim, int64_t *bm25_docs,
+                     int64_t *bm25_postings, int64_t *hbm_bytes) {
+    ANRAG_ENTER(idx);
+    if (dense_rows) *dense_rows = idx->n_rows;
+    if (dense_dim) *dense_dim = idx->dim;
+    if (bm25_docs) *bm25_docs = idx->n_docs;
+    if (bm25_postings) *bm25_postings = idx->n_postings;
+    if (hbm_bytes) *hbm_bytes = idx->hbm_bytes;
+    return ANRAG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,135 @@
+// Shared host/device definitions of libanrag.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <mutex>
+#include <vector>
+
+#include "anrag.h"
+
+namespace anrag {
+
+constexpr int kWave = 64;            // CDNA wavefront
+constexpr int kListLen = 64;         // one top-k slot per lane (ANRAG_FUSED_K_MAX)
+constexpr int kScanThreads = 1024;   // 16 waves: one scan workgroup per CU
+constexpr int kScanWaves = kScanThreads / kWave;
+constexpr int kMaxScanBlocks = 256;  // one per CU; also bounds the final merge fan-in
+constexpr uint32_t kNoRow = 0xFFFFFFFFu;
+
+void set_error(const char *fmt, ...);
+
+#define ANRAG_HIP(expr)                                                                    \
+    do {                                                                                   \
+        hipError_t e__ = (expr);                                                           \
+        if (e__ != hipSuccess) {                                                           \
+            ::anrag::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__),     \
+                               __FILE__, __LINE__);                                        \
+            return ANRAG_ERR_HIP;                                                          \
+        }                                                                                  \
+    } while (0)
+
+#define ANRAG_REQUIRE(cond, ...)                                                           \
+    do {                                                                                   \
+        if (!(cond)) {                                                                     \
+            ::anrag::set_error(__VA_ARGS__);                                               \
+            return ANRAG_ERR_INVALID;                                                      \
+        }                                                                                  \
+    } while (0)
+
+struct ProfSpan {
+    int kernel;
+    hipEvent_t start, stop;
+};
+
+}  // namespace anrag
+
+// One GPU's shard.  Everything the kernels touch lives in HBM for the index's lifetime.
+struct anrag_index {
+    int device = 0;
+    int n_cus = 256;
+    std::mutex mu;
+    hipStream_t own_primary = nullptr, own_secondary = nullptr;
+    hipStream_t primary = nullptr, secondary = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+
+    // ---- dense shard: row-major fp32, rows 16-byte aligned when dim % 4 == 0
+    float *d_emb = nullptr;
+    int64_t n_rows = 0;
+    int32_t dim = 0;
+    uint16_t *d_dense_src = nullptr;
+    int64_t *d_dense_doc = nullptr;
+    int64_t dense_doc_base = 0;
+
+    // ---- BM25 shard (see bm25.hip for the layout)
+    int64_t n_docs = 0, n_terms = 0, n_postings = 0;
+    int64_t *d_indptr = nullptr;       // n_terms + 1
+    int32_t *d_post_doc = nullptr;     // n_postings
+    double *d_post_impact = nullptr;   // n_postings: tf*(k1+1)/(tf + k1*(1-b+b*dl/avgdl)), fp64
+    double *d_idf = nullptr;           // n_terms
+    int32_t n_parts = 0, part_docs = 0;  // doc-range partitions (one workgroup each)
+    int32_t *d_part_ptr = nullptr;     // per "frequent" term: n_parts+1 offsets (relative to indptr[t])
+    int32_t *d_part_slot = nullptr;    // n_terms: row into d_part_ptr, or -1 (rare term: scan whole list)
+    uint16_t *d_bm25_src = nullptr;
+    int64_t *d_bm25_doc = nullptr;
+    int64_t bm25_doc_base = 0;
+    double bm25_k1 = 0, bm25_b = 0, bm25_avgdl = 0;
+
+    // ---- workspaces (sized at load; reused by every query on the stream that owns them)
+    float *d_blk_score_f32 = nullptr;  // [kMaxScanBlocks][kListLen]
+    uint32_t *d_blk_row_a = nullptr;
+    double *d_blk_score_f64 = nullptr;  // BM25 per-partition lists
+    uint32_t *d_blk_row_b = nullptr;
+    int32_t blk_lists_b = 0;
+    float *d_query = nullptr;           // staged queries
+    int64_t query_cap = 0;
+    uint32_t *d_allow_a = nullptr, *d_allow_b = nullptr;  // staged allow bitmaps (2048 words each)
+    int32_t *d_terms = nullptr;         // staged term ids
+    anrag_candidate *d_cand_a = nullptr, *d_cand_b = nullptr, *d_cand_out = nullptr;
+    int64_t cand_cap = 0;
+    void *h_pinned = nullptr;           // result staging
+    int64_t pinned_bytes = 0;
+    float *d_scores_f32 = nullptr;      // full score arrays for k > ANRAG_FUSED_K_MAX
+    double *d_scores_f64 = nullptr;
+    void *d_sort_tmp = nullptr;
+    int64_t sort_tmp_bytes = 0;
+    void *d_sort_buf = nullptr;
+    int64_t sort_buf_bytes = 0;
+
+    int64_t hbm_bytes = 0;
+
+    // ---- measurement
+    bool profiling = false;
+    std::vector<anrag::ProfSpan> spans;
+    std::vector<hipEvent_t> event_pool;
+    double prof_ms[ANRAG_KERNEL_COUNT] = {0};
+    int64_t prof_launches[ANRAG_KERNEL_COUNT] = {0};
+};
+
+namespace anrag {
+
+// Bracket a launch with events when profiling is on.
+struct LaunchTimer {
+    anrag_index *idx;
+    hipStream_t stream;
+    int kernel;
+    hipEvent_t start = nullptr, stop = nullptr;
+    LaunchTimer(anrag_index *i, int k, hipStream_t s);
+    ~LaunchTimer();
+};
+
+int drain_profile(anrag_index *idx);
+
+// ---- kernel launchers (each enqueues on `stream`, never syncs)
+int launch_dense_topk(anrag_index *idx, hipStream_t stream, const float *d_query, int32_t k,
+                      const uint32_t *d_allow_bits, anrag_candidate *d_out, float *d_scores_out);
+// k > ANRAG_FUSED_K_MAX: score array + radix sort (select.hip); host operands, syncs.
+int dense_search_large_k(anrag_index *idx, hipStream_t stream, const float *h_queries, int32_t n_queries, int32_t k,
+                         const uint32_t *d_allow_bits, int64_t *out_doc, float *out_score, int32_t *out_count);
+void free_bm25(anrag_index *idx);
+int launch_merge_candidates(anrag_index *idx, hipStream_t stream, const anrag_candidate *d_lists,
+                            int32_t n_lists, int32_t k, anrag_candidate *d_out);
+
+}  // namespace anrag

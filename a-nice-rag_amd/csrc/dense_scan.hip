@@ -1,0 +1,289 @@
+// K1 -- brute-force dense scan + fused top-k, batch = 1.
+//
+// Replaces src/search_engine.py:80-87 of the reference (np.stack -> np.dot -> argpartition):
+// the corpus matrix already sits in HBM row-major fp32, one query streams over it once.
+//
+// HBM-bound by construction: N*D*4 algorithmic bytes per query, 2 flop per 4 bytes.
+// Mapping (wave64):
+//   * G lanes share one row (G = 64 when D % 256 == 0: a whole wave reads 1 KiB of one row per
+//     global_load_dwordx4; D = 384 uses G = 32, i.e. two rows per wave-load, 512 B each);
+//   * a wave keeps R row-groups in flight per iteration (R*CH dwordx4 loads per lane issued
+//     before the first use), 16 waves per CU, one workgroup per CU striding the matrix;
+//   * the query slice of each lane lives in registers (CH float4), staged once per wave;
+//   * G-lane butterfly reduction, then the wave's register top-k (wave_topk.hpp);
+//   * per-workgroup LDS tree merge -> one sorted list per workgroup -> merge kernel (select.hip).
+#include "common.hpp"
+#include "wave_topk.hpp"
+
+namespace anrag {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));  // native vector: global_load_dwordx4, nt-loadable
+
+__device__ __forceinline__ float dot4(f32x4 a, f32x4 b, float acc) {
+    acc = __builtin_fmaf(a.x, b.x, acc);
+    acc = __builtin_fmaf(a.y, b.y, acc);
+    acc = __builtin_fmaf(a.z, b.z, acc);
+    acc = __builtin_fmaf(a.w, b.w, acc);
+    return acc;
+}
+
+// ---- cross-lane sum without touching LDS: DPP row ops (GFX9 encodings)
+//   0xB1 quad_perm[1,0,3,2]  0x4E quad_perm[2,3,0,1]  0x141 row_half_mirror  0x140 row_mirror
+//   0x142 row_bcast:15 (row_mask 0xA)   0x143 row_bcast:31 (row_mask 0xC)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add(float v) {
+    const int t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, false);
+    return v + __int_as_float(t);
+}
+
+// Sum over the G lanes that share a row.  The LAST lane of each group (lane % G == G-1) ends with the
+// group's sum (for G <= 16 every lane does).
+template <int G>
+__device__ __forceinline__ float group_sum(float v) {
+    if constexpr (G >= 2) v = dpp_add<0xB1, 0xF>(v);
+    if constexpr (G >= 4) v = dpp_add<0x4E, 0xF>(v);
+    if constexpr (G >= 8) v = dpp_add<0x141, 0xF>(v);
+    if constexpr (G >= 16) v = dpp_add<0x140, 0xF>(v);
+    if constexpr (G >= 32) v = dpp_add<0x142, 0xA>(v);
+    if constexpr (G >= 64) v = dpp_add<0x143, 0xC>(v);
+    return v;
+}
+
+__device__ __forceinline__ bool source_bit(const uint32_t *allow_lds, uint32_t s) {
+    return (allow_lds[s >> 5] >> (s & 31)) & 1u;
+}
+
+// G  lanes per row (64,32,16); dim % (4*G) == 0
+// CH float4 chunks per lane per row (dim / (4*G)), compile-time so the query sits in registers
+// R  row-groups in flight per wave iteration
+// FILTER  rows carry a source id and an allow bitmap is applied before selection
+// SCORES  write every row's score (large-k path / anrag_dense_scores) instead of selecting
+template <int G, int CH, int R, bool FILTER, bool SCORES>
+__global__ __launch_bounds__(kScanThreads) void dense_scan_kernel(
+    const float *__restrict__ emb, const float *__restrict__ query, int64_t n_rows, int32_t dim, int32_t k,
+    const uint16_t *__restrict__ src, const uint32_t *__restrict__ allow_bits, float *__restrict__ blk_score,
+    uint32_t *__restrict__ blk_row, float *__restrict__ scores_out) {
+    constexpr int GROUPS = kWave / G;  // rows per wave-load
+    constexpr int RW = GROUPS * R;     // rows per wave iteration
+    __shared__ float lds_s[kScanWaves * kListLen];
+    __shared__ uint32_t lds_r[kScanWaves * kListLen];
+    __shared__ uint32_t lds_allow[FILTER ? 2048 : 1];  // 65536 source ids
+
+    const int lane = lane_id();
+    const int wave = threadIdx.x / kWave;
+    const int sub = lane % G, grp = lane / G;
+    const bool leader = sub == G - 1;
+    if constexpr (FILTER) {
+        for (int i = threadIdx.x; i < 2048; i += kScanThreads) lds_allow[i] = allow_bits[i];
+        __syncthreads();
+    }
+
+    const f32x4 *__restrict__ ev = reinterpret_cast<const f32x4 *>(emb);
+    const int64_t row_f4 = dim / 4;
+    f32x4 q[CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) q[c] = reinterpret_cast<const f32x4 *>(query)[c * G + sub];
+
+    WaveTopK<float> top;
+    top.init(SCORES ? 1 : k);
+
+    const int64_t total_waves = (int64_t)gridDim.x * kScanWaves;
+    const int64_t gwave = (int64_t)blockIdx.x * kScanWaves + wave;
+    for (int64_t base = gwave * RW; base < n_rows; base += total_waves * RW) {
+        f32x4 v[R][CH];
+        int64_t row[R];
+        uint32_t sid[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            row[r] = base + r * GROUPS + grp;
+            const int64_t rc = row[r] < n_rows ? row[r] : n_rows - 1;  // clamp: tail lanes re-read the last row
+            if constexpr (FILTER) sid[r] = src[rc];                    // issued ahead of the row data
+            const f32x4 *p = ev + rc * row_f4 + sub;
+#pragma unroll
+            for (int c = 0; c < CH; ++c) v[r][c] = __builtin_nontemporal_load(p + c * G);
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            float acc = 0.f;
+#pragma unroll
+            for (int c = 0; c < CH; ++c) acc = dot4(v[r][c], q[c], acc);
+            acc = group_sum<G>(acc);
+            bool ok = row[r] < n_rows;
+            if constexpr (FILTER) ok = ok && source_bit(lds_allow, sid[r]);
+            if constexpr (SCORES) {
+                if (leader && row[r] < n_rows) scores_out[row[r]] = ok ? acc : neg_inf<float>();
+            } else {
+                const uint32_t r32 = (uint32_t)row[r];
+                top.offer_lanes(leader && ok && top.admits(acc, r32), acc, r32);
+            }
+        }
+    }
+    if constexpr (!SCORES) {
+        block_merge(top, lds_s, lds_r, kScanWaves);
+        if (wave == 0) {
+            blk_score[blockIdx.x * kListLen + lane] = top.s;
+            blk_row[blockIdx.x * kListLen + lane] = top.r;
+        }
+    }
+}
+
+// Any dim: one wave per row, scalar strided loads, query from global (L2).  Correctness path for
+// odd dimensions (the golden vectors use D = 8); not a performance path.
+__global__ __launch_bounds__(kScanThreads) void dense_scan_topk_generic_kernel(
+    const float *__restrict__ emb, const float *__restrict__ query, int64_t n_rows, int32_t dim, int32_t k,
+    const uint16_t *__restrict__ src, const uint32_t *__restrict__ allow_bits, float *__restrict__ blk_score,
+    uint32_t *__restrict__ blk_row, float *__restrict__ scores_out) {
+    __shared__ float lds_s[kScanWaves * kListLen];
+    __shared__ uint32_t lds_r[kScanWaves * kListLen];
+    __shared__ uint32_t lds_allow[2048];
+    const int lane = lane_id();
+    const int wave = threadIdx.x / kWave;
+    const bool filtered = allow_bits != nullptr;
+    if (filtered) {
+        for (int i = threadIdx.x; i < 2048; i += kScanThreads) lds_allow[i] = allow_bits[i];
+        __syncthreads();
+    }
+    WaveTopK<float> top;
+    top.init(k > 0 ? k : 1);
+    const int64_t total_waves = (int64_t)gridDim.x * kScanWaves;
+    for (int64_t row = (int64_t)blockIdx.x * kScanWaves + wave; row < n_rows; row += total_waves) {
+        const float *p = emb + row * dim;
+        float acc = 0.f;
+        for (int c = lane; c < dim; c += kWave) acc = __builtin_fmaf(p[c], query[c], acc);
+        acc = group_sum<kWave>(acc);  // total lands in lane 63
+        bool ok = true;
+        if (filtered) ok = source_bit(lds_allow, src[row]);
+        if (scores_out != nullptr && lane == kWave - 1) scores_out[row] = ok ? acc : neg_inf<float>();
+        if (k > 0) top.offer_lanes(lane == kWave - 1 && ok && top.admits(acc, (uint32_t)row), acc, (uint32_t)row);
+    }
+    if (k > 0) {
+        block_merge(top, lds_s, lds_r, kScanWaves);
+        if (wave == 0) {
+            blk_score[blockIdx.x * kListLen + lane] = top.s;
+            blk_row[blockIdx.x * kListLen + lane] = top.r;
+        }
+    }
+}
+
+// Block lists (fp32 score, local row) -> global top-k as anrag_candidate {fp64 score, doc id}.
+__global__ __launch_bounds__(256) void dense_final_merge_kernel(const float *__restrict__ blk_score,
+                                                                const uint32_t *__restrict__ blk_row,
+                                                                int32_t n_lists, int32_t k,
+                                                                const int64_t *__restrict__ doc_of_row,
+                                                                int64_t doc_base,
+                                                                anrag_candidate *__restrict__ out) {
+    constexpr int W = 4;
+    __shared__ float lds_s[W * kListLen];
+    __shared__ uint32_t lds_r[W * kListLen];
+    const int lane = lane_id(), wave = threadIdx.x / kWave;
+    WaveTopK<float> top;
+    top.init(k);
+    // pass A: the heads of this wave's lists (lane <-> list), one coalesced-ish load
+    for (int l0 = wave * kWave; l0 < n_lists; l0 += W * kWave) {
+        const int list = l0 + lane;
+        const bool have = list < n_lists;
+        const float hs = have ? blk_score[list * kListLen] : neg_inf<float>();
+        const uint32_t hr = have ? blk_row[list * kListLen] : kNoRow;
+        top.offer_lanes(have && top.admits(hs, hr), hs, hr);
+        // pass B: a list whose head is still inside the top-k may hold more winners
+        unsigned long long m = __ballot(have && hr != kNoRow && !beats(top.thr_s, top.thr_r, hs, hr));
+        while (m) {
+            const int l = __builtin_ctzll(m);
+            m &= m - 1;
+            const int li = l0 + l;
+            const float es = blk_score[li * kListLen + lane];  // lane i <- entry i, 256 B coalesced
+            const uint32_t er = blk_row[li * kListLen + lane];
+            for (int i = 1; i < k; ++i) {
+                const float cs = read_lane(es, i);
+                const uint32_t cr = read_lane(er, i);
+                if (!top.admits(cs, cr)) break;
+                top.insert(cs, cr);
+            }
+        }
+    }
+    block_merge(top, lds_s, lds_r, W);
+    if (wave == 0 && lane < k) {
+        anrag_candidate c;
+        c.score = (double)top.s;
+        c.doc = top.r == kNoRow ? -1 : (doc_of_row ? doc_of_row[top.r] : doc_base + (int64_t)top.r);
+        if (top.r == kNoRow) c.score = -__builtin_huge_val();
+        out[lane] = c;
+    }
+}
+
+template <int G, int CH>
+static void launch_scan(int grid, hipStream_t st, const anrag_index *idx, const float *q, int32_t k,
+                        const uint32_t *allow, float *scores_out) {
+    constexpr int R = (CH >= 8) ? 2 : 4;
+#define ANRAG_SCAN(F, S)                                                                                     \
+    dense_scan_kernel<G, CH, R, F, S><<<grid, kScanThreads, 0, st>>>(                                          \
+        idx->d_emb, q, idx->n_rows, idx->dim, k, idx->d_dense_src, allow, idx->d_blk_score_f32, idx->d_blk_row_a, \
+        scores_out)
+    if (scores_out) {
+        if (allow) ANRAG_SCAN(true, true); else ANRAG_SCAN(false, true);
+    } else {
+        if (allow) ANRAG_SCAN(true, false); else ANRAG_SCAN(false, false);
+    }
+#undef ANRAG_SCAN
+}
+
+int launch_dense_topk(anrag_index *idx, hipStream_t st, const float *d_query, int32_t k,
+                      const uint32_t *d_allow_bits, anrag_candidate *d_out, float *d_scores_out) {
+    const int64_t n = idx->n_rows;
+    const int d = idx->dim;
+    int grid = idx->n_cus < kMaxScanBlocks ? idx->n_cus : kMaxScanBlocks;
+    {
+        // small corpora: no more workgroups than there are wave-iterations of work
+        const int64_t need = (n + kScanWaves * 4 - 1) / (kScanWaves * 4);
+        if (need < grid) grid = (int)(need > 0 ? need : 1);
+    }
+    const uint32_t *allow = (idx->d_dense_src != nullptr) ? d_allow_bits : nullptr;
+    {
+        LaunchTimer t(idx, ANRAG_KERNEL_DENSE_SCAN, st);
+        bool done = true;
+        if (d % 256 == 0 && d / 256 <= 8) {
+            switch (d / 256) {
+                case 1: launch_scan<64, 1>(grid, st, idx, d_query, k, allow, d_scores_out); break;
+                case 2: launch_scan<64, 2>(grid, st, idx, d_query, k, allow, d_scores_out); break;
+                case 3: launch_scan<64, 3>(grid, st, idx, d_query, k, allow, d_scores_out); break;
+                case 4: launch_scan<64, 4>(grid, st, idx, d_query, k, allow, d_scores_out); break;
+                case 6: launch_scan<64, 6>(grid, st, idx, d_query, k, allow, d_scores_out); break;
+                case 8: launch_scan<64, 8>(grid, st, idx, d_query, k, allow, d_scores_out); break;
+                default: done = false;
+            }
+        } else if (d % 128 == 0 && d / 128 <= 8) {
+            switch (d / 128) {
+                case 1: launch_scan<32, 1>(grid, st, idx, d_query, k, allow, d_scores_out); break;
+                case 3: launch_scan<32, 3>(grid, st, idx, d_query, k, allow, d_scores_out); break;
+                case 5: launch_scan<32, 5>(grid, st, idx, d_query, k, allow, d_scores_out); break;
+                case 7: launch_scan<32, 7>(grid, st, idx, d_query, k, allow, d_scores_out); break;
+                default: done = false;
+            }
+        } else if (d % 64 == 0 && d / 64 <= 8) {
+            switch (d / 64) {
+                case 1: launch_scan<16, 1>(grid, st, idx, d_query, k, allow, d_scores_out); break;
+                case 3: launch_scan<16, 3>(grid, st, idx, d_query, k, allow, d_scores_out); break;
+                case 5: launch_scan<16, 5>(grid, st, idx, d_query, k, allow, d_scores_out); break;
+                case 7: launch_scan<16, 7>(grid, st, idx, d_query, k, allow, d_scores_out); break;
+                default: done = false;
+            }
+        } else {
+            done = false;
+        }
+        if (!done)
+            dense_scan_topk_generic_kernel<<<grid, kScanThreads, 0, st>>>(idx->d_emb, d_query, n, d, k,
+                                                                          idx->d_dense_src, allow,
+                                                                          idx->d_blk_score_f32, idx->d_blk_row_a,
+                                                                          d_scores_out);
+        ANRAG_HIP(hipGetLastError());
+    }
+    if (k > 0) {
+        LaunchTimer t(idx, ANRAG_KERNEL_SELECT, st);
+        dense_final_merge_kernel<<<1, 256, 0, st>>>(idx->d_blk_score_f32, idx->d_blk_row_a, grid, k, idx->d_dense_doc,
+                                                    idx->dense_doc_base, d_out);
+        ANRAG_HIP(hipGetLastError());
+    }
+    return ANRAG_OK;
+}
+
+}  // namespace anrag

@@ -1,0 +1,82 @@
+// K4 -- selection over candidate records.
+//
+//  * merge_candidates_kernel: n_lists sorted lists of k anrag_candidate records (the RCCL
+//    all-gather receive buffer of the sharded path) -> global top-k by
+//    (score desc, doc asc).  Replicated on every rank, latency-bound, one workgroup.
+#include "common.hpp"
+
+namespace anrag {
+
+// Same register top-k as wave_topk.hpp but keyed on (fp64 score, int64 doc).
+struct DocTopK {
+    double s;
+    long long d;
+    double thr_s;
+    long long thr_d;
+    int k;
+    static __device__ __forceinline__ bool beats(double s, long long d, double ts, long long td) {
+        // an empty slot is doc -1 / -inf and loses to everything real
+        if (td < 0) return d >= 0;
+        if (d < 0) return false;
+        return s > ts || (s == ts && d < td);
+    }
+    __device__ __forceinline__ void init(int k_) {
+        s = -__builtin_huge_val();
+        d = -1;
+        thr_s = s;
+        thr_d = -1;
+        k = k_;
+    }
+    __device__ __forceinline__ bool admits(double cs, long long cd) const { return beats(cs, cd, thr_s, thr_d); }
+    __device__ __forceinline__ void insert(double cs, long long cd) {
+        const int lane = threadIdx.x & 63;
+        const bool ahead = beats(s, d, cs, cd);
+        const double up_s = __shfl_up(s, 1);
+        const long long up_d = __shfl_up(d, 1);
+        const int up_ahead = __shfl_up((int)ahead, 1);
+        if (!ahead) {
+            const bool first = (lane == 0) || up_ahead;
+            s = first ? cs : up_s;
+            d = first ? cd : up_d;
+        }
+        thr_s = __shfl(s, k - 1);
+        thr_d = __shfl(d, k - 1);
+    }
+};
+
+__global__ __launch_bounds__(64) void merge_candidates_kernel(const anrag_candidate *__restrict__ lists,
+                                                              int32_t n_lists, int32_t k,
+                                                              anrag_candidate *__restrict__ out) {
+    const int lane = threadIdx.x;
+    DocTopK top;
+    top.init(k);
+    for (int li = 0; li < n_lists; ++li) {
+        // lane i <- record i of the list (k <= 64), then a uniform walk until the first loser
+        anrag_candidate c;
+        c.score = -__builtin_huge_val();
+        c.doc = -1;
+        if (lane < k) c = lists[(int64_t)li * k + lane];
+        for (int i = 0; i < k; ++i) {
+            const double cs = __shfl(c.score, i);
+            const long long cd = __shfl((long long)c.doc, i);
+            if (!top.admits(cs, cd)) break;
+            top.insert(cs, cd);
+        }
+    }
+    if (lane < k) {
+        anrag_candidate c;
+        c.score = top.d < 0 ? -__builtin_huge_val() : top.s;
+        c.doc = top.d;
+        out[lane] = c;
+    }
+}
+
+int launch_merge_candidates(anrag_index *idx, hipStream_t st, const anrag_candidate *d_lists, int32_t n_lists,
+                            int32_t k, anrag_candidate *d_out) {
+    LaunchTimer t(idx, ANRAG_KERNEL_SELECT, st);
+    merge_candidates_kernel<<<1, 64, 0, st>>>(d_lists, n_lists, k, d_out);
+    ANRAG_HIP(hipGetLastError());
+    return ANRAG_OK;
+}
+
+}  // namespace anrag

@@ -1,0 +1,114 @@
+// Per-wavefront top-k kept in registers: lane i holds the i-th best candidate.
+//
+// Order: score descending, then row ascending (a total order: rows are unique),
+// which is the build's deterministic reading of the reference's selection at
+// src/search_engine.py:83-87 / :233 / :236-243.  An empty slot is
+// (-inf, kNoRow): the minimum of that order, so real rows with score -inf or 0
+// still rank (the reference does not drop zero-score BM25 documents).
+// NaN never beats anything and is therefore never selected (documented gap:
+// numpy would rank NaN first).
+#pragma once
+#include "common.hpp"
+
+namespace anrag {
+
+template <typename S>
+__device__ __forceinline__ S neg_inf();
+template <>
+__device__ __forceinline__ float neg_inf<float>() { return -__builtin_huge_valf(); }
+template <>
+__device__ __forceinline__ double neg_inf<double>() { return -__builtin_huge_val(); }
+
+template <typename S>
+__device__ __forceinline__ bool beats(S s, uint32_t r, S ts, uint32_t tr) {
+    return s > ts || (s == ts && r < tr);
+}
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & (kWave - 1); }
+
+// Wave-uniform read of one lane's value (v_readlane_b32: SGPR result).
+__device__ __forceinline__ uint32_t read_lane(uint32_t v, int l) {
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, l);
+}
+__device__ __forceinline__ float read_lane(float v, int l) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+}
+__device__ __forceinline__ double read_lane(double v, int l) {
+    long long b = __double_as_longlong(v);
+    uint32_t lo = read_lane((uint32_t)b, l), hi = read_lane((uint32_t)((unsigned long long)b >> 32), l);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
+template <typename S>
+struct WaveTopK {
+    S s;          // this lane's slot
+    uint32_t r;
+    S thr_s;      // wave-uniform copy of slot k-1 (what a newcomer has to beat)
+    uint32_t thr_r;
+    int k;
+
+    __device__ __forceinline__ void init(int k_) {
+        s = neg_inf<S>();
+        r = kNoRow;
+        thr_s = neg_inf<S>();
+        thr_r = kNoRow;
+        k = k_;
+    }
+    __device__ __forceinline__ bool admits(S cs, uint32_t cr) const { return beats(cs, cr, thr_s, thr_r); }
+
+    // Insert a wave-uniform candidate that admits() accepted: every slot it outranks moves down one lane.
+    __device__ __forceinline__ void insert(S cs, uint32_t cr) {
+        const int lane = lane_id();
+        const bool ahead = beats(s, r, cs, cr);  // this slot outranks the newcomer
+        const S up_s = __shfl_up(s, 1);
+        const uint32_t up_r = __shfl_up(r, 1);
+        const int up_ahead = __shfl_up((int)ahead, 1);
+        if (!ahead) {
+            const bool first = (lane == 0) || up_ahead;
+            s = first ? cs : up_s;
+            r = first ? cr : up_r;
+        }
+        thr_s = read_lane(s, k - 1);
+        thr_r = read_lane(r, k - 1);
+    }
+
+    // Offer one candidate per flagged lane (flag already includes admits()); wave-uniform loop.
+    __device__ __forceinline__ void offer_lanes(bool flag, S cs, uint32_t cr) {
+        unsigned long long m = __ballot(flag);
+        while (m) {
+            const int l = __builtin_ctzll(m);
+            m &= m - 1;
+            const S us = read_lane(cs, l);
+            const uint32_t ur = read_lane(cr, l);
+            if (admits(us, ur)) insert(us, ur);
+        }
+    }
+
+    // Merge a sorted list that lives in LDS/global (uniform reads), stopping at the first loser.
+    __device__ __forceinline__ void merge_sorted(const S *ls, const uint32_t *lr) {
+        for (int i = 0; i < k; ++i) {
+            const S cs = ls[i];
+            const uint32_t cr = lr[i];
+            if (!admits(cs, cr)) break;
+            insert(cs, cr);
+        }
+    }
+};
+
+// Tree-merge the per-wave lists of one workgroup through LDS; wave 0 ends up with the block's top-k.
+// lds_s / lds_r: [n_waves][kListLen].  All waves must call this (it has barriers).
+template <typename S>
+__device__ __forceinline__ void block_merge(WaveTopK<S> &t, S *lds_s, uint32_t *lds_r, int n_waves) {
+    const int wave = threadIdx.x / kWave, lane = lane_id();
+    for (int half = n_waves >> 1; half >= 1; half >>= 1) {
+        if (wave >= half && wave < 2 * half) {
+            lds_s[wave * kListLen + lane] = t.s;
+            lds_r[wave * kListLen + lane] = t.r;
+        }
+        __syncthreads();
+        if (wave < half) t.merge_sorted(lds_s + (wave + half) * kListLen, lds_r + (wave + half) * kListLen);
+        __syncthreads();
+    }
+}
+
+}  // namespace anrag

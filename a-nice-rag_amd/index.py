@@ -1,0 +1,222 @@
+"""`Index`: one GPU's shard (corpus rows + postings) resident in HBM, over the C ABI.
+
+Thin, numpy-in / numpy-out; no torch types here.  The reference-shaped classes
+(`database_manager.DatabaseManager`, `search_engine.SearchEngine`) sit on top.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _native as nat
+
+
+def _f32(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _allow_bytes(allow) -> Tuple[Optional[np.ndarray], int]:
+    if allow is None:
+        return None, 0
+    a = np.ascontiguousarray(allow, dtype=np.uint8)
+    return a, int(a.size)
+
+
+class Index:
+    """Owns an `anrag_index*`.  Not copyable; `close()` (or GC) frees the HBM."""
+
+    def __init__(self, device: int = 0):
+        self._lib = nat.load_library()
+        h = C.c_void_p()
+        nat.check(self._lib.anrag_index_create(int(device), C.byref(h)))
+        self._h = h
+        self.device = int(device)
+        self.n_rows = 0
+        self.dim = 0
+        self.n_docs = 0
+
+    # ------------------------------------------------------------------ lifetime
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            self._lib.anrag_index_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    @property
+    def handle(self) -> C.c_void_p:
+        if not self._h:
+            raise nat.AnragError(-3, "index is closed")
+        return self._h
+
+    def set_streams(self, primary: int = 0, secondary: int = 0) -> None:
+        """Run on caller-owned HIP streams (e.g. torch.cuda.current_stream().cuda_stream)."""
+        nat.check(self._lib.anrag_index_set_streams(self.handle, primary or None, secondary or None))
+
+    def sync(self) -> None:
+        nat.check(self._lib.anrag_index_sync(self.handle))
+
+    # ------------------------------------------------------------------ dense
+    def dense_load(self, embeddings, source_id=None, doc_id=None, doc_id_base: int = 0) -> None:
+        """Upload the row-major fp32 corpus matrix (numpy array, or an (address, n, d) tuple of a
+        device buffer such as a torch tensor's data_ptr())."""
+        if isinstance(embeddings, tuple):
+            addr, n, d = embeddings
+            keep = None
+        else:
+            keep = _f32(embeddings)
+            assert keep.ndim == 2
+            n, d = keep.shape
+            addr = keep.ctypes.data
+        src = None if source_id is None else np.ascontiguousarray(source_id, dtype=np.uint16)
+        doc = None if doc_id is None else np.ascontiguousarray(doc_id, dtype=np.int64)
+        assert src is None or src.shape == (n,)
+        assert doc is None or doc.shape == (n,)
+        nat.check(self._lib.anrag_dense_load(self.handle, addr, n, d, nat.ptr(src), nat.ptr(doc), int(doc_id_base)))
+        self.n_rows, self.dim = int(n), int(d)
+
+    def dense_search(self, queries, k: int, allow_source=None):
+        """-> (doc [nq,k] int64, score [nq,k] float32, count [nq] int32); rank order, tail = -1/-inf."""
+        q = _f32(queries)
+        if q.ndim == 1:
+            q = q[None, :]
+        if self.n_rows == 0:
+            raise nat.AnragError(-3, "dense search before dense_load")
+        assert q.shape[1] == self.dim, f"query dim {q.shape[1]} != index dim {self.dim}"
+        nq = q.shape[0]
+        allow, ns = _allow_bytes(allow_source)
+        doc = np.empty((nq, k), np.int64)
+        score = np.empty((nq, k), np.float32)
+        count = np.empty(nq, np.int32)
+        nat.check(self._lib.anrag_dense_search(self.handle, q.ctypes.data, nq, int(k), nat.ptr(allow), ns,
+                                               doc.ctypes.data, score.ctypes.data, count.ctypes.data))
+        return doc, score, count
+
+    def dense_scores(self, query) -> np.ndarray:
+        q = _f32(query).reshape(-1)
+        assert q.size == self.dim
+        out = np.empty(self.n_rows, np.float32)
+        nat.check(self._lib.anrag_dense_scores(self.handle, q.ctypes.data, out.ctypes.data))
+        return out
+
+    def dense_search_device(self, d_queries: int, n_queries: int, k: int, d_allow_bits: int, d_out: int) -> None:
+        nat.check(self._lib.anrag_dense_search_device(self.handle, d_queries, n_queries, k, d_allow_bits or None, d_out))
+
+    # ------------------------------------------------------------------ BM25
+    def bm25_load(self, indptr, post_doc, post_tf, idf, doc_len, avgdl: float, k1: float, b: float,
+                  source_id=None, doc_id=None, doc_id_base: int = 0) -> None:
+        indptr = np.ascontiguousarray(indptr, dtype=np.int64)
+        post_doc = np.ascontiguousarray(post_doc, dtype=np.int32)
+        post_tf = np.ascontiguousarray(post_tf, dtype=np.int32)
+        idf = np.ascontiguousarray(idf, dtype=np.float64)
+        doc_len = np.ascontiguousarray(doc_len, dtype=np.int32)
+        n_terms, n_docs = indptr.size - 1, doc_len.size
+        assert idf.size == n_terms and post_doc.size == post_tf.size == int(indptr[-1])
+        src = None if source_id is None else np.ascontiguousarray(source_id, dtype=np.uint16)
+        doc = None if doc_id is None else np.ascontiguousarray(doc_id, dtype=np.int64)
+        nat.check(self._lib.anrag_bm25_load(self.handle, indptr.ctypes.data, n_terms, nat.ptr(post_doc),
+                                            nat.ptr(post_tf), idf.ctypes.data, doc_len.ctypes.data, n_docs,
+                                            float(avgdl), float(k1), float(b), nat.ptr(src), nat.ptr(doc),
+                                            int(doc_id_base)))
+        self.n_docs = int(n_docs)
+
+    def bm25_search(self, term_ids: Sequence[int], k: int, allow_source=None):
+        """-> (doc [k] int64, score [k] float64, count)."""
+        t = np.ascontiguousarray(term_ids, dtype=np.int32)
+        allow, ns = _allow_bytes(allow_source)
+        doc = np.empty(k, np.int64)
+        score = np.empty(k, np.float64)
+        count = np.zeros(1, np.int32)
+        nat.check(self._lib.anrag_bm25_search(self.handle, nat.ptr(t) if t.size else None, int(t.size), int(k),
+                                              nat.ptr(allow), ns, doc.ctypes.data, score.ctypes.data,
+                                              count.ctypes.data))
+        return doc, score, int(count[0])
+
+    def bm25_scores(self, term_ids: Sequence[int]) -> np.ndarray:
+        t = np.ascontiguousarray(term_ids, dtype=np.int32)
+        out = np.empty(self.n_docs, np.float64)
+        nat.check(self._lib.anrag_bm25_scores(self.handle, nat.ptr(t) if t.size else None, int(t.size),
+                                              out.ctypes.data))
+        return out
+
+    # ------------------------------------------------------------------ fusion
+    def wrrf(self, lists: Sequence[Sequence[int]], weights: Sequence[float], k: float, top_n: int):
+        """-> (id [m] int64, score [m] float64), m = min(top_n, distinct ids)."""
+        ids = np.ascontiguousarray(np.concatenate([np.asarray(l, dtype=np.int64) for l in lists])
+                                   if len(lists) else np.empty(0, np.int64))
+        lens = np.ascontiguousarray([len(l) for l in lists], dtype=np.int32)
+        w = np.ascontiguousarray(weights, dtype=np.float64)
+        top_n = int(min(top_n, max(ids.size, 1)))
+        out_id = np.empty(top_n, np.int64)
+        out_score = np.empty(top_n, np.float64)
+        count = np.zeros(1, np.int32)
+        nat.check(self._lib.anrag_wrrf(self.handle, nat.ptr(ids) if ids.size else None, lens.ctypes.data,
+                                       w.ctypes.data, len(lists), float(k), top_n, out_id.ctypes.data,
+                                       out_score.ctypes.data, count.ctypes.data))
+        m = int(count[0])
+        return out_id[:m], out_score[:m]
+
+    def hybrid_search(self, query, term_ids: Sequence[int], similarity_k: int, w_dense: float, w_bm25: float,
+                      wrrf_k: float, top_n: int, allow_dense=None, allow_bm25=None):
+        q = _f32(query).reshape(-1)
+        assert q.size == self.dim
+        t = np.ascontiguousarray(term_ids, dtype=np.int32)
+        ad, nd = _allow_bytes(allow_dense)
+        ab, nb = _allow_bytes(allow_bm25)
+        out_id = np.empty(top_n, np.int64)
+        out_score = np.empty(top_n, np.float64)
+        count = np.zeros(1, np.int32)
+        nat.check(self._lib.anrag_hybrid_search(self.handle, q.ctypes.data, nat.ptr(t) if t.size else None,
+                                                int(t.size), int(similarity_k), float(w_dense), float(w_bm25),
+                                                float(wrrf_k), int(top_n), nat.ptr(ad), nd, nat.ptr(ab), nb,
+                                                out_id.ctypes.data, out_score.ctypes.data, count.ctypes.data))
+        m = int(count[0])
+        return out_id[:m], out_score[:m]
+
+    # ------------------------------------------------------------------ measurement
+    def profile(self, on: bool) -> None:
+        nat.check(self._lib.anrag_profile_enable(self.handle, 1 if on else 0))
+
+    def profile_reset(self) -> None:
+        nat.check(self._lib.anrag_profile_reset(self.handle))
+
+    def profile_read(self, kernel_id: int) -> Tuple[float, int]:
+        ms = C.c_double(0)
+        n = C.c_int64(0)
+        nat.check(self._lib.anrag_profile_read(self.handle, int(kernel_id), C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def info(self) -> dict:
+        a, d, b, p, h = C.c_int64(), C.c_int32(), C.c_int64(), C.c_int64(), C.c_int64()
+        nat.check(self._lib.anrag_index_info(self.handle, C.byref(a), C.byref(d), C.byref(b), C.byref(p), C.byref(h)))
+        return dict(dense_rows=a.value, dense_dim=d.value, bm25_docs=b.value, bm25_postings=p.value,
+                    hbm_bytes=h.value)
+
+    # raw device memory (for callers without torch)
+    def device_alloc(self, nbytes: int) -> int:
+        p = C.c_void_p()
+        nat.check(self._lib.anrag_device_alloc(self.handle, int(nbytes), C.byref(p)))
+        return p.value
+
+    def device_free(self, addr: int) -> None:
+        nat.check(self._lib.anrag_device_free(self.handle, addr))
+
+    def to_device(self, addr: int, arr: np.ndarray) -> None:
+        a = np.ascontiguousarray(arr)
+        nat.check(self._lib.anrag_copy_to_device(self.handle, addr, a.ctypes.data, a.nbytes))
+
+    def to_host(self, arr: np.ndarray, addr: int) -> None:
+        assert arr.flags["C_CONTIGUOUS"]
+        nat.check(self._lib.anrag_copy_to_host(self.handle, arr.ctypes.data, addr, arr.nbytes))

@@ -1,0 +1,221 @@
+/*
+ * anrag.h -- C ABI of libanrag.so: the MI355X (gfx950) retrieval hot path of
+ * A-NICE-RAG (dense dot-product top-k, BM25 term-at-a-time top-k, weighted
+ * reciprocal-rank fusion) behind plain pointers and sizes.
+ *
+ * The reference has no FFI of its own: its boundary is the Python method surface
+ * of `SearchEngine` (src/search_engine.py:14-293) and `DatabaseManager`
+ * (src/database_manager.py:14-99).  Each entry point below names the reference
+ * lines it replaces; the Python binding a maintainer would add is shown in
+ * INTEGRATION.md and shipped in a-nice-rag_amd/_native.py.
+ *
+ * Conventions
+ *   - every function returns ANRAG_OK (0) or a negative ANRAG_ERR_*; the message
+ *     of the last failure on the calling thread is anrag_last_error().  Nothing
+ *     throws or aborts across this boundary (the reference's own convention is
+ *     "log and return empty", search_engine.py:94-98, :267-269 -- the Python
+ *     shim maps error codes back to that).
+ *   - "host" pointers are ordinary process memory; "device" pointers are HBM
+ *     addresses of the index's GPU (hipMalloc / torch tensor .data_ptr()).
+ *   - one anrag_index = one GPU's shard: a row block of the corpus matrix and
+ *     the postings of the same documents.  Calls on one index are serialised by
+ *     an internal mutex (the reference shares one SearchEngine between Streamlit
+ *     session threads, src/app.py:17-27); different indexes are independent.
+ *   - document identity inside the library is an int64 "doc id" chosen by the
+ *     caller (a global id space shared by the dense rows and the BM25 rows, so
+ *     that fusion can run on ids as the reference fuses on chunk-id strings,
+ *     search_engine.py:27-32).  Strings never cross the boundary.
+ *   - ordering rule everywhere: score descending, then ROW ascending (rows are
+ *     what the reference's tie behaviour is stated in: its filtered BM25 path is
+ *     a stable sort = low row first, :233; its numpy paths leave ties
+ *     unspecified).  Across shards the tie-break is doc id ascending, which is
+ *     the same thing under row sharding with doc id = doc_id_base + row.
+ */
+#ifndef ANRAG_H
+#define ANRAG_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ANRAG_ABI_VERSION 1
+
+#define ANRAG_OK 0
+#define ANRAG_ERR_INVALID (-1) /* bad argument                                   */
+#define ANRAG_ERR_HIP (-2)     /* a HIP runtime call failed                      */
+#define ANRAG_ERR_STATE (-3)   /* e.g. search before load                        */
+#define ANRAG_ERR_NOMEM (-4)   /* host or device allocation failed               */
+#define ANRAG_ERR_NODEVICE (-5) /* no usable gfx950 device                       */
+
+/* Largest k served by the fused in-register per-wave top-k (one candidate per
+ * lane of a 64-wide wavefront).  Larger k (retrieval_eval.py:142-143 uses 12000)
+ * takes the score-array + radix-sort path; both are exact. */
+#define ANRAG_FUSED_K_MAX 64
+
+/* Candidate record exchanged between shards (RCCL all-gather payload) and
+ * consumed by anrag_merge_candidates_device: 16 bytes, score widened to fp64
+ * (exact for the dense fp32 scores). Unused slots: doc = -1, score = -inf. */
+typedef struct anrag_candidate {
+    double score;
+    int64_t doc;
+} anrag_candidate;
+
+typedef struct anrag_index anrag_index;
+
+/* Kernel ids for anrag_profile_read */
+#define ANRAG_KERNEL_DENSE_SCAN 0    /* K1: N x D fp32 scan + per-wave top-k      */
+#define ANRAG_KERNEL_DENSE_BATCHED 1 /* K2: Q x N fp32 MFMA GEMM + top-k epilogue */
+#define ANRAG_KERNEL_BM25 2          /* K3: CSR postings scorer                   */
+#define ANRAG_KERNEL_SELECT 3        /* K4: candidate merge / score-array select  */
+#define ANRAG_KERNEL_WRRF 4          /* K5: weighted RRF + top-n                  */
+#define ANRAG_KERNEL_COUNT 5
+
+/* ------------------------------------------------------------------ library */
+int anrag_abi_version(void);
+const char *anrag_last_error(void);
+int anrag_device_count(int *out_count);
+
+/* ------------------------------------------------------------------ index lifetime
+ * Replaces the process-lifetime DataFrame / pickle caches of DatabaseManager
+ * (database_manager.py:17-18, :65-66, :92-93): the index owns the HBM copies. */
+int anrag_index_create(int device, anrag_index **out);
+int anrag_index_destroy(anrag_index *idx);
+/* Run the index's kernels on caller-owned HIP streams (hipStream_t as void*),
+ * e.g. torch.cuda.current_stream().cuda_stream so that RCCL collectives issued
+ * through torch.distributed order after them.  NULL = the index's own streams.
+ * `secondary` carries the BM25 leg of a hybrid search concurrently with the
+ * dense scan on `primary`. */
+int anrag_index_set_streams(anrag_index *idx, void *primary, void *secondary);
+/* Block until everything enqueued on the index's streams has finished. */
+int anrag_index_sync(anrag_index *idx);
+
+/* ------------------------------------------------------------------ dense: load
+ * The upload point that replaces per-row np.frombuffer + DataFrame
+ * (database_manager.py:39-66) and the per-query np.stack (search_engine.py:80):
+ * `embeddings` is the row-major n_rows x dim fp32 matrix (host or device
+ * pointer), copied once into HBM.
+ *   source_id  nullable, n_rows x uint16: interned `source` string of each row
+ *              (the column the filter of search_engine.py:36-55 looks at)
+ *   doc_id     nullable, n_rows x int64: global doc id of each row; NULL means
+ *              doc id = doc_id_base + row */
+int anrag_dense_load(anrag_index *idx, const float *embeddings, int64_t n_rows, int32_t dim,
+                     const uint16_t *source_id, const int64_t *doc_id, int64_t doc_id_base);
+
+/* ------------------------------------------------------------------ dense: search
+ * SearchEngine.similarity_search_with_embedding, search_engine.py:57-98 (and the
+ * arithmetic of similarity_search, :100-146): raw dot product of each query with
+ * every allowed row, top-k by (score desc, row asc).
+ *   queries       host, n_queries x dim fp32 (the reference is batch=1,
+ *                 search_engine.py:77-81; n_queries > 1 = that loop, batched)
+ *   allow_source  nullable host, n_sources bytes: allow_source[s] != 0 keeps rows
+ *                 whose source_id == s (the Python shim evaluates the reference's
+ *                 prefix/regex rule once per distinct source string)
+ *   out_doc / out_score   host, n_queries x k, rank order; unused tail: -1 / -inf
+ *   out_count     host, n_queries: entries returned (min(k, allowed rows)) */
+int anrag_dense_search(anrag_index *idx, const float *queries, int32_t n_queries, int32_t k,
+                       const uint8_t *allow_source, int32_t n_sources, int64_t *out_doc,
+                       float *out_score, int32_t *out_count);
+
+/* Same, all operands in HBM, enqueued on the primary stream, no host sync:
+ * d_out is n_queries x k anrag_candidate.  Used for back-to-back query streams
+ * and for the sharded path (the output is the all-gather send buffer).
+ * d_allow_bits: nullable device bitmap, bit s of word s/32 = source s allowed. */
+int anrag_dense_search_device(anrag_index *idx, const float *d_queries, int32_t n_queries,
+                              int32_t k, const uint32_t *d_allow_bits, anrag_candidate *d_out);
+
+/* All N scores of one query (what search_engine.py:81 materialises), for tests
+ * and for callers that post-process scores themselves.  out: host, n_rows fp32. */
+int anrag_dense_scores(anrag_index *idx, const float *query, float *out_scores);
+
+/* ------------------------------------------------------------------ BM25: load
+ * Replaces the pickled rank_bm25.BM25Okapi object (database_manager.py:77-99;
+ * built at processing/bm25_search.py:77): term-major CSR postings plus the
+ * statistics BM25Okapi.__init__ derives.  All host pointers.
+ *   indptr    n_terms+1 offsets into post_doc/post_tf; documents strictly
+ *             ascending inside each term
+ *   post_doc  document ROW (0..n_docs-1) of each posting;  post_tf  term frequency
+ *   idf       n_terms, already epsilon-floored (Python floats from math.log)
+ *   doc_len   n_docs token counts;  avgdl, k1, b as BM25Okapi holds them
+ *   source_id / doc_id / doc_id_base   as for anrag_dense_load (BM25 rows are a
+ *             different row space from the dense rows: bm25_search.py:67-68) */
+int anrag_bm25_load(anrag_index *idx, const int64_t *indptr, int64_t n_terms,
+                    const int32_t *post_doc, const int32_t *post_tf, const double *idf,
+                    const int32_t *doc_len, int64_t n_docs, double avgdl, double k1, double b,
+                    const uint16_t *source_id, const int64_t *doc_id, int64_t doc_id_base);
+
+/* ------------------------------------------------------------------ BM25: search
+ * SearchEngine._core_bm25_search, search_engine.py:205-243, including the
+ * bm25.get_scores call at :219 (rank_bm25 arithmetic: fp64, term-at-a-time in
+ * query order, duplicates counted again).  term_ids: host, query tokens mapped
+ * to term ids IN QUERY ORDER; a negative id = token not in the vocabulary
+ * (contributes nothing).  Zero-score documents are ranked, not dropped.
+ * Bit-exact fp64 scores; order (score desc, row asc). */
+int anrag_bm25_search(anrag_index *idx, const int32_t *term_ids, int32_t n_terms, int32_t k,
+                      const uint8_t *allow_source, int32_t n_sources, int64_t *out_doc,
+                      double *out_score, int32_t *out_count);
+int anrag_bm25_search_device(anrag_index *idx, const int32_t *d_term_ids, int32_t n_terms,
+                             int32_t k, const uint32_t *d_allow_bits, anrag_candidate *d_out);
+/* BM25Okapi.get_scores(query) itself: out host, n_docs fp64. */
+int anrag_bm25_scores(anrag_index *idx, const int32_t *term_ids, int32_t n_terms,
+                      double *out_scores);
+
+/* ------------------------------------------------------------------ fusion
+ * SearchEngine.weighted_reciprocal_rank_fusion, search_engine.py:21-34, followed
+ * by the caller's truncation to common_sections_n (query_rag_retrieval.py:360-362):
+ *   score[id] += weight[l] * (1 / (k + rank)), rank from 1, lists in order;
+ *   stable sort by score descending (ties keep first-insertion order).
+ * ids: host, the lists concatenated; list_len[l] entries each. fp64, bit-exact. */
+int anrag_wrrf(anrag_index *idx, const int64_t *ids, const int32_t *list_len,
+               const double *weight, int32_t n_lists, double k, int32_t top_n, int64_t *out_id,
+               double *out_score, int32_t *out_count);
+
+/* ------------------------------------------------------------------ fused hybrid query
+ * The body of retrieve_documents for one dense model + BM25
+ * (query_rag_retrieval.py:197-220, :304-335, :356-378) in one call: dense scan on
+ * the primary stream, BM25 on the secondary, WRRF + top-n on the device.
+ * n_terms == 0 or w_bm25 <= 0 skips BM25 (then the dense list is returned, :363-366).
+ * allow_* as above, one per row space. */
+int anrag_hybrid_search(anrag_index *idx, const float *query, const int32_t *term_ids,
+                        int32_t n_terms, int32_t similarity_k, double w_dense, double w_bm25,
+                        double wrrf_k, int32_t top_n, const uint8_t *allow_dense,
+                        int32_t n_dense_sources, const uint8_t *allow_bm25,
+                        int32_t n_bm25_sources, int64_t *out_id, double *out_score,
+                        int32_t *out_count);
+
+/* ------------------------------------------------------------------ sharded merge
+ * After an all-gather of every shard's k candidates: merge n_lists sorted lists of
+ * k records each into the global top-k (score desc, doc asc -- row order is
+ * shard-local, doc ids are global and ascend with rows under row sharding).
+ * All device pointers; enqueued on the primary stream. */
+int anrag_merge_candidates_device(anrag_index *idx, const anrag_candidate *d_lists,
+                                  int32_t n_lists, int32_t k, anrag_candidate *d_out);
+/* WRRF over two device candidate lists (dense, bm25) -> top_n on the device. */
+int anrag_wrrf_device(anrag_index *idx, const anrag_candidate *d_dense, int32_t n_dense,
+                      const anrag_candidate *d_bm25, int32_t n_bm25, double w_dense,
+                      double w_bm25, double k, int32_t top_n, anrag_candidate *d_out);
+
+/* ------------------------------------------------------------------ device memory helpers
+ * (so a pure-ctypes caller can stage operands without torch) */
+int anrag_device_alloc(anrag_index *idx, int64_t bytes, void **out_ptr);
+int anrag_device_free(anrag_index *idx, void *ptr);
+int anrag_copy_to_device(anrag_index *idx, void *d_dst, const void *h_src, int64_t bytes);
+int anrag_copy_to_host(anrag_index *idx, void *h_dst, const void *d_src, int64_t bytes);
+
+/* ------------------------------------------------------------------ measurement
+ * With profiling on, every launch of the kernels above is bracketed by HIP events
+ * on the stream it runs on; anrag_profile_read drains them (syncs the streams)
+ * and returns the summed device time and launch count of one kernel id since
+ * the last reset. */
+int anrag_profile_enable(anrag_index *idx, int on);
+int anrag_profile_reset(anrag_index *idx);
+int anrag_profile_read(anrag_index *idx, int kernel_id, double *out_total_ms, int64_t *out_launches);
+/* Shape facts a caller needs for roofline arithmetic. */
+int anrag_index_info(anrag_index *idx, int64_t *dense_rows, int32_t *dense_dim,
+                     int64_t *bm25_docs, int64_t *bm25_postings, int64_t *hbm_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ANRAG_H */
