@@ -4,6 +4,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <vector>
 
 #include "common.hpp"
 
@@ -229,6 +230,7 @@ int anrag_index_destroy(anrag_index *idx) {
                         idx->d_cand_out,      idx->d_scores_f64, idx->d_sort_tmp,     idx->d_sort_buf};
         for (void *p : ptrs)
             if (p) (void)hipFree(p);
+        free_wrrf_scratch(idx);
         if (idx->h_pinned) (void)hipHostFree(idx->h_pinned);
         for (hipEvent_t e : idx->event_pool) (void)hipEventDestroy(e);
         if (idx->ev_fork) (void)hipEventDestroy(idx->ev_fork);
@@ -359,6 +361,242 @@ int anrag_dense_search(anrag_index *idx, const float *queries, int32_t n_queries
             out_count[q0 + qi] = cnt;
         }
     }
+    return ANRAG_OK;
+}
+
+// ------------------------------------------------------------------ BM25
+int anrag_bm25_load(anrag_index *idx, const int64_t *indptr, int64_t n_terms, const int32_t *post_doc,
+                    const int32_t *post_tf, const double *idf, const int32_t *doc_len, int64_t n_docs, double avgdl,
+                    double k1, double b, const uint16_t *source_id, const int64_t *doc_id, int64_t doc_id_base) {
+    ANRAG_ENTER(idx);
+    int rc = ensure_common_workspace(idx);
+    if (rc) return rc;
+    return bm25_load(idx, indptr, n_terms, post_doc, post_tf, idf, doc_len, n_docs, avgdl, k1, b, source_id, doc_id,
+                     doc_id_base);
+}
+
+static int stage_terms(anrag_index *idx, hipStream_t st, const int32_t *term_ids, int32_t n_terms) {
+    ANRAG_REQUIRE(n_terms >= 0 && n_terms <= 4096, "n_terms %d out of range [0, 4096]", n_terms);
+    ANRAG_REQUIRE(n_terms == 0 || term_ids != nullptr, "term_ids is NULL");
+    if (n_terms > 0)
+        ANRAG_HIP(hipMemcpyAsync(idx->d_terms, term_ids, (size_t)n_terms * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    return ANRAG_OK;
+}
+
+int anrag_bm25_search_device(anrag_index *idx, const int32_t *d_term_ids, int32_t n_terms, int32_t k,
+                             const uint32_t *d_allow_bits, anrag_candidate *d_out) {
+    ANRAG_ENTER(idx);
+    ANRAG_REQUIRE(idx->d_post_doc != nullptr, "BM25 search before anrag_bm25_load");
+    ANRAG_REQUIRE(d_out && (n_terms == 0 || d_term_ids), "NULL operand");
+    ANRAG_REQUIRE(n_terms >= 0, "n_terms must be >= 0");
+    ANRAG_REQUIRE(k > 0 && k <= ANRAG_FUSED_K_MAX, "device path serves 1 <= k <= %d (got %d)", ANRAG_FUSED_K_MAX, k);
+    return launch_bm25(idx, idx->primary, d_term_ids, n_terms, k, d_allow_bits, d_out, nullptr);
+}
+
+int anrag_bm25_search(anrag_index *idx, const int32_t *term_ids, int32_t n_terms, int32_t k,
+                      const uint8_t *allow_source, int32_t n_sources, int64_t *out_doc, double *out_score,
+                      int32_t *out_count) {
+    ANRAG_ENTER(idx);
+    ANRAG_REQUIRE(idx->d_post_doc != nullptr, "BM25 search before anrag_bm25_load");
+    ANRAG_REQUIRE(out_doc && out_score && out_count, "NULL operand");
+    ANRAG_REQUIRE(k > 0, "k must be positive");
+    ANRAG_REQUIRE(!(allow_source && !idx->d_bm25_src), "a source filter needs source ids (anrag_bm25_load)");
+    hipStream_t st = idx->primary;
+    int rc;
+    const uint32_t *d_allow = nullptr;
+    uint32_t *h_bits = reinterpret_cast<uint32_t *>(static_cast<char *>(idx->h_pinned) + 8192);
+    if ((rc = stage_allow(idx, st, allow_source, n_sources, idx->d_allow_b, h_bits, &d_allow))) return rc;
+    if ((rc = stage_terms(idx, st, term_ids, n_terms))) return rc;
+    if (k > ANRAG_FUSED_K_MAX)
+        return bm25_search_large_k(idx, st, idx->d_terms, n_terms, k, d_allow, out_doc, out_score, out_count);
+    if ((rc = launch_bm25(idx, st, idx->d_terms, n_terms, k, d_allow, idx->d_cand_out, nullptr))) return rc;
+    anrag_candidate *h_cand = reinterpret_cast<anrag_candidate *>(static_cast<char *>(idx->h_pinned) + 16384);
+    ANRAG_HIP(hipMemcpyAsync(h_cand, idx->d_cand_out, (size_t)k * sizeof(anrag_candidate), hipMemcpyDeviceToHost, st));
+    ANRAG_HIP(hipStreamSynchronize(st));
+    int32_t cnt = 0;
+    for (int32_t i = 0; i < k; ++i) {
+        out_doc[i] = h_cand[i].doc;
+        out_score[i] = h_cand[i].score;
+        if (h_cand[i].doc >= 0) ++cnt;
+    }
+    *out_count = cnt;
+    return ANRAG_OK;
+}
+
+int anrag_bm25_scores(anrag_index *idx, const int32_t *term_ids, int32_t n_terms, double *out_scores) {
+    ANRAG_ENTER(idx);
+    ANRAG_REQUIRE(idx->d_post_doc != nullptr, "BM25 scores before anrag_bm25_load");
+    ANRAG_REQUIRE(out_scores != nullptr, "NULL operand");
+    hipStream_t st = idx->primary;
+    int rc;
+    if ((rc = stage_terms(idx, st, term_ids, n_terms))) return rc;
+    if (!idx->d_scores_f64) {
+        ANRAG_HIP(hipMalloc(reinterpret_cast<void **>(&idx->d_scores_f64), (size_t)idx->n_docs * sizeof(double)));
+        idx->hbm_bytes += idx->n_docs * 8;
+        idx->bm25_hbm_bytes += idx->n_docs * 8;
+    }
+    if ((rc = launch_bm25(idx, st, idx->d_terms, n_terms, 0, nullptr, nullptr, idx->d_scores_f64))) return rc;
+    ANRAG_HIP(hipMemcpyAsync(out_scores, idx->d_scores_f64, (size_t)idx->n_docs * sizeof(double),
+                             hipMemcpyDeviceToHost, st));
+    ANRAG_HIP(hipStreamSynchronize(st));
+    return ANRAG_OK;
+}
+
+// ------------------------------------------------------------------ fusion
+int anrag_wrrf(anrag_index *idx, const int64_t *ids, const int32_t *list_len, const double *weight, int32_t n_lists,
+               double k, int32_t top_n, int64_t *out_id, double *out_score, int32_t *out_count) {
+    ANRAG_ENTER(idx);
+    ANRAG_REQUIRE(list_len && weight && out_id && out_score && out_count, "NULL operand");
+    ANRAG_REQUIRE(n_lists >= 1 && n_lists <= ANRAG_WRRF_MAX_LISTS, "n_lists %d out of range [1, %d]", n_lists,
+                  ANRAG_WRRF_MAX_LISTS);
+    ANRAG_REQUIRE(top_n > 0, "top_n must be positive");
+    int32_t off[ANRAG_WRRF_MAX_LISTS + 1];
+    off[0] = 0;
+    for (int l = 0; l < n_lists; ++l) {
+        ANRAG_REQUIRE(list_len[l] >= 0, "negative list length");
+        ANRAG_REQUIRE((int64_t)off[l] + list_len[l] < 0x7FFFFFFF, "lists too long");
+        off[l + 1] = off[l] + list_len[l];
+    }
+    const int32_t m = off[n_lists];
+    *out_count = 0;
+    if (m == 0) return ANRAG_OK;
+    ANRAG_REQUIRE(ids != nullptr, "ids is NULL");
+    hipStream_t st = idx->primary;
+    int rc;
+    if ((rc = ensure_wrrf_scratch(idx, m))) return rc;
+    ANRAG_HIP(hipMemcpyAsync(idx->d_w_in, ids, (size_t)m * sizeof(int64_t), hipMemcpyHostToDevice, st));
+    if ((rc = launch_wrrf(idx, st, idx->d_w_in, nullptr, off, weight, n_lists, k, top_n, idx->d_w_out, idx->d_w_count)))
+        return rc;
+    int32_t cnt = 0;
+    ANRAG_HIP(hipMemcpyAsync(&cnt, idx->d_w_count, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    ANRAG_HIP(hipStreamSynchronize(st));
+    cnt = std::min(cnt, std::min(top_n, m));
+    std::vector<anrag_candidate> h((size_t)cnt);
+    if (cnt > 0) {
+        ANRAG_HIP(hipMemcpyAsync(h.data(), idx->d_w_out, (size_t)cnt * sizeof(anrag_candidate), hipMemcpyDeviceToHost, st));
+        ANRAG_HIP(hipStreamSynchronize(st));
+    }
+    for (int32_t i = 0; i < cnt; ++i) {
+        out_id[i] = h[i].doc;
+        out_score[i] = h[i].score;
+    }
+    *out_count = cnt;
+    return ANRAG_OK;
+}
+
+int anrag_wrrf_device(anrag_index *idx, const anrag_candidate *d_dense, int32_t n_dense,
+                      const anrag_candidate *d_bm25, int32_t n_bm25, double w_dense, double w_bm25, double k,
+                      int32_t top_n, anrag_candidate *d_out, int32_t *d_count) {
+    ANRAG_ENTER(idx);
+    ANRAG_REQUIRE(d_dense && d_out && d_count, "NULL operand");
+    ANRAG_REQUIRE(n_dense >= 0 && n_bm25 >= 0 && n_dense + n_bm25 > 0 && n_dense + n_bm25 <= 1024,
+                  "need 0 < n_dense + n_bm25 <= 1024");
+    ANRAG_REQUIRE(top_n > 0, "top_n must be positive");
+    hipStream_t st = idx->primary;
+    int rc;
+    if ((rc = ensure_common_workspace(idx))) return rc;
+    // the two lists have to be contiguous for the kernel: stage them in the index's candidate buffer
+    ANRAG_HIP(hipMemcpyAsync(idx->d_cand_a, d_dense, (size_t)n_dense * sizeof(anrag_candidate), hipMemcpyDeviceToDevice, st));
+    if (n_bm25 > 0)
+        ANRAG_HIP(hipMemcpyAsync(idx->d_cand_a + n_dense, d_bm25, (size_t)n_bm25 * sizeof(anrag_candidate),
+                                 hipMemcpyDeviceToDevice, st));
+    const int32_t off[3] = {0, n_dense, n_dense + n_bm25};
+    const double w[2] = {w_dense, w_bm25};
+    return launch_wrrf(idx, st, nullptr, idx->d_cand_a, off, w, n_bm25 > 0 ? 2 : 1, k, top_n, d_out, d_count);
+}
+
+// ------------------------------------------------------------------ fused hybrid query
+// dense on `primary`, BM25 on `secondary`, WRRF on `primary` after the join; nothing syncs the host.
+static int hybrid_enqueue(anrag_index *idx, const float *d_query, const int32_t *d_terms, int32_t n_terms,
+                          int32_t similarity_k, double w_dense, double w_bm25, double wrrf_k, int32_t top_n,
+                          const uint32_t *d_allow_dense, const uint32_t *d_allow_bm25, anrag_candidate *d_out,
+                          int32_t *d_count) {
+    const bool use_bm25 = idx->d_post_doc != nullptr && n_terms > 0 && w_bm25 > 0.0;
+    const bool use_dense = idx->d_emb != nullptr && w_dense > 0.0;
+    ANRAG_REQUIRE(use_dense || use_bm25, "hybrid search with neither a dense nor a BM25 leg");
+    hipStream_t P = idx->primary, S = idx->secondary;
+    anrag_candidate *dense_out = idx->d_cand_a, *bm25_out = idx->d_cand_a + (use_dense ? similarity_k : 0);
+    int rc;
+    if (use_bm25) {
+        // S must not overwrite its slot while the previous query's fusion (on P) may still read it
+        ANRAG_HIP(hipEventRecord(idx->ev_fork, P));
+        ANRAG_HIP(hipStreamWaitEvent(S, idx->ev_fork, 0));
+        if ((rc = launch_bm25(idx, S, d_terms, n_terms, similarity_k, d_allow_bm25, bm25_out, nullptr))) return rc;
+        ANRAG_HIP(hipEventRecord(idx->ev_join, S));
+    }
+    if (use_dense)
+        if ((rc = launch_dense_topk(idx, P, d_query, similarity_k, d_allow_dense, dense_out, nullptr))) return rc;
+    if (use_bm25) ANRAG_HIP(hipStreamWaitEvent(P, idx->ev_join, 0));
+    int32_t off[3] = {0, 0, 0};
+    double w[2] = {0, 0};
+    int n_lists = 0;
+    if (use_dense) {
+        w[n_lists] = w_dense;
+        off[n_lists + 1] = off[n_lists] + similarity_k;
+        ++n_lists;
+    }
+    if (use_bm25) {
+        w[n_lists] = w_bm25;
+        off[n_lists + 1] = off[n_lists] + similarity_k;
+        ++n_lists;
+    }
+    return launch_wrrf(idx, P, nullptr, idx->d_cand_a, off, w, n_lists, wrrf_k, top_n, d_out, d_count);
+}
+
+int anrag_hybrid_search_device(anrag_index *idx, const float *d_query, const int32_t *d_term_ids, int32_t n_terms,
+                               int32_t similarity_k, double w_dense, double w_bm25, double wrrf_k, int32_t top_n,
+                               const uint32_t *d_allow_dense_bits, const uint32_t *d_allow_bm25_bits,
+                               anrag_candidate *d_out, int32_t *d_count) {
+    ANRAG_ENTER(idx);
+    ANRAG_REQUIRE(d_out && d_count, "NULL operand");
+    ANRAG_REQUIRE(similarity_k > 0 && similarity_k <= ANRAG_FUSED_K_MAX, "fused hybrid serves 1 <= similarity_k <= %d",
+                  ANRAG_FUSED_K_MAX);
+    ANRAG_REQUIRE(top_n > 0 && top_n <= 2 * ANRAG_FUSED_K_MAX, "top_n %d out of range", top_n);
+    return hybrid_enqueue(idx, d_query, d_term_ids, n_terms, similarity_k, w_dense, w_bm25, wrrf_k, top_n,
+                          d_allow_dense_bits, d_allow_bm25_bits, d_out, d_count);
+}
+
+int anrag_hybrid_search(anrag_index *idx, const float *query, const int32_t *term_ids, int32_t n_terms,
+                        int32_t similarity_k, double w_dense, double w_bm25, double wrrf_k, int32_t top_n,
+                        const uint8_t *allow_dense, int32_t n_dense_sources, const uint8_t *allow_bm25,
+                        int32_t n_bm25_sources, int64_t *out_id, double *out_score, int32_t *out_count) {
+    ANRAG_ENTER(idx);
+    ANRAG_REQUIRE(out_id && out_score && out_count, "NULL operand");
+    ANRAG_REQUIRE(similarity_k > 0 && similarity_k <= ANRAG_FUSED_K_MAX, "fused hybrid serves 1 <= similarity_k <= %d",
+                  ANRAG_FUSED_K_MAX);
+    ANRAG_REQUIRE(top_n > 0 && top_n <= 2 * ANRAG_FUSED_K_MAX, "top_n %d out of range", top_n);
+    ANRAG_REQUIRE(!(allow_dense && !idx->d_dense_src) && !(allow_bm25 && !idx->d_bm25_src),
+                  "a source filter needs source ids");
+    hipStream_t P = idx->primary;
+    int rc;
+    if ((rc = ensure_common_workspace(idx))) return rc;
+    if ((rc = ensure_wrrf_scratch(idx, 4096))) return rc;
+    char *pin = static_cast<char *>(idx->h_pinned);
+    const uint32_t *d_ad = nullptr, *d_ab = nullptr;
+    if ((rc = stage_allow(idx, P, allow_dense, n_dense_sources, idx->d_allow_a, reinterpret_cast<uint32_t *>(pin), &d_ad)))
+        return rc;
+    if ((rc = stage_allow(idx, P, allow_bm25, n_bm25_sources, idx->d_allow_b, reinterpret_cast<uint32_t *>(pin + 8192),
+                          &d_ab)))
+        return rc;
+    if (idx->d_emb && w_dense > 0.0) {
+        ANRAG_REQUIRE(query != nullptr, "query is NULL");
+        ANRAG_HIP(hipMemcpyAsync(idx->d_query, query, (size_t)idx->dim * sizeof(float), hipMemcpyHostToDevice, P));
+    }
+    if ((rc = stage_terms(idx, P, term_ids, n_terms))) return rc;
+    if ((rc = hybrid_enqueue(idx, idx->d_query, idx->d_terms, n_terms, similarity_k, w_dense, w_bm25, wrrf_k, top_n,
+                             d_ad, d_ab, idx->d_w_out, idx->d_w_count)))
+        return rc;
+    anrag_candidate *h_cand = reinterpret_cast<anrag_candidate *>(pin + 16384);
+    int32_t *h_cnt = reinterpret_cast<int32_t *>(pin + 16384 + 4096);
+    ANRAG_HIP(hipMemcpyAsync(h_cand, idx->d_w_out, (size_t)top_n * sizeof(anrag_candidate), hipMemcpyDeviceToHost, P));
+    ANRAG_HIP(hipMemcpyAsync(h_cnt, idx->d_w_count, sizeof(int32_t), hipMemcpyDeviceToHost, P));
+    ANRAG_HIP(hipStreamSynchronize(P));
+    const int32_t cnt = std::min(*h_cnt, top_n);
+    for (int32_t i = 0; i < cnt; ++i) {
+        out_id[i] = h_cand[i].doc;
+        out_score[i] = h_cand[i].score;
+    }
+    *out_count = cnt;
     return ANRAG_OK;
 }
 

@@ -1,0 +1,353 @@
+// K3 -- BM25 term-at-a-time scorer over CSR postings + fused top-k.
+//
+// Replaces `bm25.get_scores(tokens)` (rank_bm25.BM25Okapi, called at src/search_engine.py:219) and the
+// selection that follows it (:221-243).  Bit-exact fp64: the reference evaluates, per query token q in
+// query order (duplicates again),
+//     score += idf[q] * ( tf*(k1+1) / ( tf + k1*(1 - b + b*dl/avgdl) ) )
+// as numpy fp64 vector expressions, i.e. separately rounded *, /, + in exactly that association.
+// The library is built with -ffp-contract=off, fp64 division on gfx950 is correctly rounded, and the
+// per-document accumulation order below is the query order, so every score has the same bits.
+//
+// MI355X design (not the reference's shape):
+//   * load time: the bracketed factor depends only on (tf, document), so it is evaluated ONCE per
+//     posting on the device (same association) and stored as an fp64 "impact" next to the doc id:
+//     a posting is 12 bytes in HBM and a query touches no doc_len / tf at all.
+//   * documents are cut into partitions of P <= 4096 consecutive rows; one workgroup owns one
+//     partition and keeps its fp64 score slice in LDS (32 KB), so there is no N-sized score array to
+//     clear, scatter into and re-read (the reference's np.zeros(N) + N-long adds per token):
+//     HBM traffic per query is the postings themselves.
+//   * terms are walked in query order inside the workgroup with a barrier between terms: two
+//     postings of one term never hit the same document, postings of different terms are ordered.
+//   * frequent terms (df >= kFrequentDf) carry a per-partition offset table built at load time, so a
+//     workgroup reads only its own slice of the posting list; rare terms are scanned whole (<= 8 KB
+//     of doc ids, L2-resident across the workgroups) and range-checked.
+//   * selection runs on the LDS slice (wave_topk.hpp), zero-score documents included, as the
+//     reference ranks them (:236-243); one sorted list per partition -> merge kernel (select.hip).
+#include <algorithm>
+#include <vector>
+
+#include "common.hpp"
+#include "wave_topk.hpp"
+
+namespace anrag {
+
+constexpr int kBm25Threads = 256;
+constexpr int kBm25Waves = kBm25Threads / kWave;
+constexpr int kMaxPartDocs = 4096;
+constexpr int kFrequentDf = 2048;
+constexpr int kTermBatch = 128;
+
+// ------------------------------------------------------------------ load-time kernels
+__global__ void bm25_impact_kernel(const int32_t *__restrict__ post_doc, const int32_t *__restrict__ post_tf,
+                                   const int32_t *__restrict__ doc_len, int64_t n_postings, double k1, double b,
+                                   double avgdl, double *__restrict__ impact) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_postings) return;
+    const double f = (double)post_tf[i];
+    const double dl = (double)doc_len[post_doc[i]];
+    // q_freq * (k1 + 1) / (q_freq + k1 * (1 - b + b * doc_len / avgdl))   -- rank_bm25, numpy fp64
+    const double num = f * (k1 + 1.0);
+    const double den = f + k1 * ((1.0 - b) + (b * dl) / avgdl);
+    impact[i] = num / den;
+}
+
+// part_ptr[slot][p] = first posting of the term whose doc >= p * part_docs (relative to indptr[term])
+__global__ void bm25_part_ptr_kernel(const int64_t *__restrict__ indptr, const int32_t *__restrict__ post_doc,
+                                     const int32_t *__restrict__ slot_term, int32_t n_slots, int32_t n_parts,
+                                     int32_t part_docs, int32_t *__restrict__ part_ptr) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t total = (int64_t)n_slots * (n_parts + 1);
+    if (gid >= total) return;
+    const int32_t slot = (int32_t)(gid / (n_parts + 1)), p = (int32_t)(gid % (n_parts + 1));
+    const int32_t t = slot_term[slot];
+    const int64_t base = indptr[t];
+    const int32_t df = (int32_t)(indptr[t + 1] - base);
+    const int64_t target = (int64_t)p * part_docs;
+    int32_t lo = 0, hi = df;  // lower_bound
+    while (lo < hi) {
+        const int32_t mid = (lo + hi) >> 1;
+        if ((int64_t)post_doc[base + mid] < target) lo = mid + 1; else hi = mid;
+    }
+    part_ptr[gid] = lo;
+}
+
+// ------------------------------------------------------------------ query kernel
+template <bool FILTER, bool SCORES>
+__global__ __launch_bounds__(kBm25Threads) void bm25_kernel(
+    const int64_t *__restrict__ indptr, const int32_t *__restrict__ post_doc, const double *__restrict__ impact,
+    const double *__restrict__ idf, const int32_t *__restrict__ part_slot, const int32_t *__restrict__ part_ptr,
+    int32_t n_parts, int32_t part_docs, int64_t n_docs, int64_t n_vocab, const int32_t *__restrict__ terms,
+    int32_t n_terms, int32_t k, const uint16_t *__restrict__ src, const uint32_t *__restrict__ allow_bits,
+    double *__restrict__ blk_score, uint32_t *__restrict__ blk_row, double *__restrict__ scores_out) {
+    __shared__ double slice[kMaxPartDocs];
+    __shared__ double t_w[kTermBatch];
+    __shared__ int64_t t_base[kTermBatch];
+    __shared__ int32_t t_begin[kTermBatch], t_end[kTermBatch], t_scan[kTermBatch];
+    __shared__ double lds_s[kBm25Waves * kListLen];
+    __shared__ uint32_t lds_r[kBm25Waves * kListLen];
+    __shared__ uint32_t lds_allow[FILTER ? 2048 : 1];
+
+    const int tid = threadIdx.x, lane = lane_id(), wave = tid / kWave;
+    const int32_t part = blockIdx.x;
+    const int64_t lo = (int64_t)part * part_docs;
+    const int64_t hi = lo + part_docs < n_docs ? lo + part_docs : n_docs;
+    const int32_t len = (int32_t)(hi - lo);
+
+    for (int i = tid; i < part_docs; i += kBm25Threads) slice[i] = 0.0;
+    if constexpr (FILTER)
+        for (int i = tid; i < 2048; i += kBm25Threads) lds_allow[i] = allow_bits[i];
+
+    for (int32_t b0 = 0; b0 < n_terms; b0 += kTermBatch) {
+        const int32_t nb = n_terms - b0 < kTermBatch ? n_terms - b0 : kTermBatch;
+        __syncthreads();  // slice zeroed / previous batch's table no longer read
+        if (tid < nb) {
+            const int32_t t = terms[b0 + tid];
+            double w = 0.0;
+            int64_t base = 0;
+            int32_t a = 0, e = 0, scan = 0;
+            if (t >= 0 && (int64_t)t < n_vocab) {
+                w = idf[t];  // `(idf.get(q) or 0)`: an idf of exactly 0 contributes nothing
+                base = indptr[t];
+                const int32_t slot = part_slot[t];
+                if (slot >= 0) {
+                    a = part_ptr[(int64_t)slot * (n_parts + 1) + part];
+                    e = part_ptr[(int64_t)slot * (n_parts + 1) + part + 1];
+                } else {
+                    e = (int32_t)(indptr[t + 1] - base);
+                    scan = 1;
+                }
+            }
+            t_w[tid] = w;
+            t_base[tid] = base;
+            t_begin[tid] = a;
+            t_end[tid] = e;
+            t_scan[tid] = scan;
+        }
+        __syncthreads();
+        for (int32_t j = 0; j < nb; ++j) {
+            const double w = t_w[j];
+            if (w != 0.0) {
+                const int64_t base = t_base[j];
+                const int32_t e = t_end[j];
+                if (t_scan[j]) {
+                    for (int32_t i = tid; i < e; i += kBm25Threads) {
+                        const int64_t d = post_doc[base + i];
+                        if (d >= lo && d < hi) slice[d - lo] = slice[d - lo] + w * impact[base + i];
+                    }
+                } else {
+                    for (int32_t i = t_begin[j] + tid; i < e; i += kBm25Threads) {
+                        const int32_t d = post_doc[base + i] - (int32_t)lo;
+                        slice[d] = slice[d] + w * impact[base + i];
+                    }
+                }
+            }
+            __syncthreads();  // term j is complete before term j+1 may touch the same document
+        }
+    }
+    if (n_terms == 0) __syncthreads();
+
+    if constexpr (SCORES) {
+        for (int i = tid; i < len; i += kBm25Threads) {
+            bool ok = true;
+            if constexpr (FILTER) ok = source_ok(lds_allow, src[lo + i]);
+            scores_out[lo + i] = ok ? slice[i] : neg_inf<double>();
+        }
+    } else {
+        WaveTopK<double> top;
+        top.init(k);
+        for (int i0 = 0; i0 < len; i0 += kBm25Threads) {
+            const int i = i0 + tid;
+            bool ok = i < len;
+            double s = neg_inf<double>();
+            if (ok) {
+                s = slice[i];
+                if constexpr (FILTER) ok = source_ok(lds_allow, src[lo + i]);
+            }
+            const uint32_t r = (uint32_t)(lo + i);
+            top.offer_lanes(ok && top.admits(s, r), s, r);
+        }
+        block_merge(top, lds_s, lds_r, kBm25Waves);
+        if (wave == 0) {
+            blk_score[blockIdx.x * kListLen + lane] = top.s;
+            blk_row[blockIdx.x * kListLen + lane] = top.r;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ host side
+void free_bm25(anrag_index *idx) {
+    void *ptrs[] = {idx->d_indptr,   idx->d_post_doc,  idx->d_post_impact, idx->d_idf,
+                    idx->d_part_ptr, idx->d_part_slot, idx->d_bm25_src,    idx->d_bm25_doc};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    idx->d_indptr = nullptr;
+    idx->d_post_doc = nullptr;
+    idx->d_post_impact = nullptr;
+    idx->d_idf = nullptr;
+    idx->d_part_ptr = nullptr;
+    idx->d_part_slot = nullptr;
+    idx->d_bm25_src = nullptr;
+    idx->d_bm25_doc = nullptr;
+    if (idx->d_scores_f64) (void)hipFree(idx->d_scores_f64);
+    idx->d_scores_f64 = nullptr;
+    idx->hbm_bytes -= idx->bm25_hbm_bytes;
+    idx->bm25_hbm_bytes = 0;
+    idx->n_docs = idx->n_terms = idx->n_postings = 0;
+}
+
+template <typename T>
+static int bm25_alloc(anrag_index *idx, T **p, int64_t count) {
+    *p = nullptr;
+    if (count <= 0) count = 1;
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(p), (size_t)count * sizeof(T));
+    if (e != hipSuccess) {
+        set_error("hipMalloc(%lld bytes) failed: %s", (long long)(count * (int64_t)sizeof(T)), hipGetErrorString(e));
+        return ANRAG_ERR_NOMEM;
+    }
+    idx->hbm_bytes += count * (int64_t)sizeof(T);
+    idx->bm25_hbm_bytes += count * (int64_t)sizeof(T);
+    return ANRAG_OK;
+}
+
+int bm25_load(anrag_index *idx, const int64_t *indptr, int64_t n_terms, const int32_t *post_doc,
+              const int32_t *post_tf, const double *idf, const int32_t *doc_len, int64_t n_docs, double avgdl,
+              double k1, double b, const uint16_t *source_id, const int64_t *doc_id, int64_t doc_id_base) {
+    ANRAG_REQUIRE(indptr && post_doc && post_tf && idf && doc_len, "NULL operand");
+    ANRAG_REQUIRE(n_terms > 0 && n_terms < 0x7FFFFFFF, "n_terms %lld out of range", (long long)n_terms);
+    ANRAG_REQUIRE(n_docs > 0 && n_docs < 0x7FFFFFFF, "n_docs %lld out of range (1 .. 2^31-2 per shard)",
+                  (long long)n_docs);
+    ANRAG_REQUIRE(indptr[0] == 0, "indptr[0] must be 0");
+    ANRAG_REQUIRE(avgdl > 0.0, "avgdl must be positive");
+    const int64_t n_postings = indptr[n_terms];
+    for (int64_t t = 0; t < n_terms; ++t) {
+        ANRAG_REQUIRE(indptr[t + 1] >= indptr[t], "indptr not monotone at term %lld", (long long)t);
+        ANRAG_REQUIRE(indptr[t + 1] - indptr[t] <= n_docs, "term %lld has more postings than documents", (long long)t);
+    }
+    ANRAG_HIP(hipStreamSynchronize(idx->primary));
+    ANRAG_HIP(hipStreamSynchronize(idx->secondary));
+    free_bm25(idx);
+    int rc;
+    idx->n_docs = n_docs;
+    idx->n_terms = n_terms;
+    idx->n_postings = n_postings;
+    idx->bm25_k1 = k1;
+    idx->bm25_b = b;
+    idx->bm25_avgdl = avgdl;
+    idx->bm25_doc_base = doc_id_base;
+    // partitioning: about one workgroup per CU, slices of at most 32 KB
+    int64_t pd = (n_docs + idx->n_cus - 1) / idx->n_cus;
+    pd = ((pd + 255) / 256) * 256;
+    pd = std::max<int64_t>(256, std::min<int64_t>(kMaxPartDocs, pd));
+    idx->part_docs = (int32_t)pd;
+    idx->n_parts = (int32_t)((n_docs + pd - 1) / pd);
+
+    if ((rc = bm25_alloc(idx, &idx->d_indptr, n_terms + 1))) return rc;
+    if ((rc = bm25_alloc(idx, &idx->d_post_doc, n_postings))) return rc;
+    if ((rc = bm25_alloc(idx, &idx->d_post_impact, n_postings))) return rc;
+    if ((rc = bm25_alloc(idx, &idx->d_idf, n_terms))) return rc;
+    if ((rc = bm25_alloc(idx, &idx->d_part_slot, n_terms))) return rc;
+    ANRAG_HIP(hipMemcpy(idx->d_indptr, indptr, (size_t)(n_terms + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
+    ANRAG_HIP(hipMemcpy(idx->d_idf, idf, (size_t)n_terms * sizeof(double), hipMemcpyHostToDevice));
+    if (n_postings > 0)
+        ANRAG_HIP(hipMemcpy(idx->d_post_doc, post_doc, (size_t)n_postings * sizeof(int32_t), hipMemcpyDefault));
+
+    // impacts: tf and doc_len are only needed here
+    {
+        int32_t *d_tf = nullptr, *d_dl = nullptr;
+        ANRAG_HIP(hipMalloc(reinterpret_cast<void **>(&d_tf), (size_t)std::max<int64_t>(n_postings, 1) * 4));
+        hipError_t e = hipMalloc(reinterpret_cast<void **>(&d_dl), (size_t)n_docs * 4);
+        if (e != hipSuccess) {
+            (void)hipFree(d_tf);
+            set_error("hipMalloc failed: %s", hipGetErrorString(e));
+            return ANRAG_ERR_NOMEM;
+        }
+        e = hipMemcpy(d_dl, doc_len, (size_t)n_docs * 4, hipMemcpyHostToDevice);
+        if (e == hipSuccess && n_postings > 0) e = hipMemcpy(d_tf, post_tf, (size_t)n_postings * 4, hipMemcpyDefault);
+        if (e == hipSuccess && n_postings > 0) {
+            const int64_t blocks = (n_postings + 255) / 256;
+            bm25_impact_kernel<<<(unsigned)blocks, 256, 0, idx->primary>>>(idx->d_post_doc, d_tf, d_dl, n_postings, k1,
+                                                                           b, avgdl, idx->d_post_impact);
+            e = hipGetLastError();
+            if (e == hipSuccess) e = hipStreamSynchronize(idx->primary);
+        }
+        (void)hipFree(d_tf);
+        (void)hipFree(d_dl);
+        if (e != hipSuccess) {
+            set_error("BM25 impact build failed: %s", hipGetErrorString(e));
+            return ANRAG_ERR_HIP;
+        }
+    }
+    // per-partition offsets of the frequent terms
+    {
+        std::vector<int32_t> slot(n_terms, -1), slot_term;
+        for (int64_t t = 0; t < n_terms; ++t)
+            if (indptr[t + 1] - indptr[t] >= kFrequentDf) {
+                slot[t] = (int32_t)slot_term.size();
+                slot_term.push_back((int32_t)t);
+            }
+        ANRAG_HIP(hipMemcpy(idx->d_part_slot, slot.data(), (size_t)n_terms * 4, hipMemcpyHostToDevice));
+        const int64_t n_slots = (int64_t)slot_term.size();
+        if ((rc = bm25_alloc(idx, &idx->d_part_ptr, n_slots * (idx->n_parts + 1)))) return rc;
+        if (n_slots > 0) {
+            int32_t *d_slot_term = nullptr;
+            ANRAG_HIP(hipMalloc(reinterpret_cast<void **>(&d_slot_term), (size_t)n_slots * 4));
+            hipError_t e = hipMemcpy(d_slot_term, slot_term.data(), (size_t)n_slots * 4, hipMemcpyHostToDevice);
+            if (e == hipSuccess) {
+                const int64_t total = n_slots * (idx->n_parts + 1);
+                bm25_part_ptr_kernel<<<(unsigned)((total + 255) / 256), 256, 0, idx->primary>>>(
+                    idx->d_indptr, idx->d_post_doc, d_slot_term, (int32_t)n_slots, idx->n_parts, idx->part_docs,
+                    idx->d_part_ptr);
+                e = hipGetLastError();
+                if (e == hipSuccess) e = hipStreamSynchronize(idx->primary);
+            }
+            (void)hipFree(d_slot_term);
+            if (e != hipSuccess) {
+                set_error("BM25 partition table build failed: %s", hipGetErrorString(e));
+                return ANRAG_ERR_HIP;
+            }
+        }
+    }
+    if (source_id) {
+        if ((rc = bm25_alloc(idx, &idx->d_bm25_src, n_docs))) return rc;
+        ANRAG_HIP(hipMemcpy(idx->d_bm25_src, source_id, (size_t)n_docs * sizeof(uint16_t), hipMemcpyDefault));
+    }
+    if (doc_id) {
+        if ((rc = bm25_alloc(idx, &idx->d_bm25_doc, n_docs))) return rc;
+        ANRAG_HIP(hipMemcpy(idx->d_bm25_doc, doc_id, (size_t)n_docs * sizeof(int64_t), hipMemcpyDefault));
+    }
+    // per-partition candidate lists
+    if (idx->d_blk_score_f64) (void)hipFree(idx->d_blk_score_f64);
+    if (idx->d_blk_row_b) (void)hipFree(idx->d_blk_row_b);
+    idx->d_blk_score_f64 = nullptr;
+    idx->d_blk_row_b = nullptr;
+    ANRAG_HIP(hipMalloc(reinterpret_cast<void **>(&idx->d_blk_score_f64), (size_t)idx->n_parts * kListLen * 8));
+    ANRAG_HIP(hipMalloc(reinterpret_cast<void **>(&idx->d_blk_row_b), (size_t)idx->n_parts * kListLen * 4));
+    idx->blk_lists_b = idx->n_parts;
+    return ANRAG_OK;
+}
+
+int launch_bm25(anrag_index *idx, hipStream_t st, const int32_t *d_terms, int32_t n_terms, int32_t k,
+                const uint32_t *d_allow_bits, anrag_candidate *d_out, double *d_scores_out) {
+    const uint32_t *allow = idx->d_bm25_src ? d_allow_bits : nullptr;
+    {
+        LaunchTimer t(idx, ANRAG_KERNEL_BM25, st);
+#define ANRAG_BM25(F, S)                                                                                          \
+    bm25_kernel<F, S><<<idx->n_parts, kBm25Threads, 0, st>>>(                                                      \
+        idx->d_indptr, idx->d_post_doc, idx->d_post_impact, idx->d_idf, idx->d_part_slot, idx->d_part_ptr,        \
+        idx->n_parts, idx->part_docs, idx->n_docs, idx->n_terms, d_terms, n_terms, k, idx->d_bm25_src, allow,     \
+        idx->d_blk_score_f64, idx->d_blk_row_b, d_scores_out)
+        if (d_scores_out) {
+            if (allow) ANRAG_BM25(true, true); else ANRAG_BM25(false, true);
+        } else {
+            if (allow) ANRAG_BM25(true, false); else ANRAG_BM25(false, false);
+        }
+#undef ANRAG_BM25
+        ANRAG_HIP(hipGetLastError());
+    }
+    if (!d_scores_out)
+        return launch_merge_block_lists_f64(idx, st, idx->d_blk_score_f64, idx->d_blk_row_b, idx->n_parts, k,
+                                            idx->d_bm25_doc, idx->bm25_doc_base, d_out);
+    return ANRAG_OK;
+}
+
+}  // namespace anrag

@@ -5,6 +5,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <limits>
 #include <mutex>
 #include <vector>
 
@@ -97,8 +98,15 @@ struct anrag_index {
     int64_t sort_tmp_bytes = 0;
     void *d_sort_buf = nullptr;
     int64_t sort_buf_bytes = 0;
+    // WRRF scratch
+    int64_t *d_w_ids = nullptr, *d_w_in = nullptr;
+    double *d_w_contrib = nullptr, *d_w_score = nullptr;
+    int32_t *d_w_first = nullptr, *d_w_count = nullptr;
+    anrag_candidate *d_w_out = nullptr;
+    int64_t wrrf_cap = 0;
 
     int64_t hbm_bytes = 0;
+    int64_t bm25_hbm_bytes = 0;
 
     // ---- measurement
     bool profiling = false;
@@ -129,6 +137,27 @@ int launch_dense_topk(anrag_index *idx, hipStream_t stream, const float *d_query
 int dense_search_large_k(anrag_index *idx, hipStream_t stream, const float *h_queries, int32_t n_queries, int32_t k,
                          const uint32_t *d_allow_bits, int64_t *out_doc, float *out_score, int32_t *out_count);
 void free_bm25(anrag_index *idx);
+int bm25_load(anrag_index *idx, const int64_t *indptr, int64_t n_terms, const int32_t *post_doc,
+              const int32_t *post_tf, const double *idf, const int32_t *doc_len, int64_t n_docs, double avgdl,
+              double k1, double b, const uint16_t *source_id, const int64_t *doc_id, int64_t doc_id_base);
+// d_out: k candidates (fused path, k <= 64) -- or d_scores_out: all n_docs scores; exactly one non-null
+int launch_bm25(anrag_index *idx, hipStream_t stream, const int32_t *d_terms, int32_t n_terms, int32_t k,
+                const uint32_t *d_allow_bits, anrag_candidate *d_out, double *d_scores_out);
+int bm25_search_large_k(anrag_index *idx, hipStream_t stream, const int32_t *d_terms, int32_t n_terms, int32_t k,
+                        const uint32_t *d_allow_bits, int64_t *out_doc, double *out_score, int32_t *out_count);
+int launch_merge_block_lists_f32(anrag_index *idx, hipStream_t st, const float *blk_score, const uint32_t *blk_row,
+                                 int32_t n_lists, int32_t k, const int64_t *doc_of_row, int64_t doc_base,
+                                 anrag_candidate *d_out);
+int launch_merge_block_lists_f64(anrag_index *idx, hipStream_t st, const double *blk_score, const uint32_t *blk_row,
+                                 int32_t n_lists, int32_t k, const int64_t *doc_of_row, int64_t doc_base,
+                                 anrag_candidate *d_out);
+// WRRF over `n_lists` id lists laid out back to back in d_ids or d_cands (list l = [h_off[l], h_off[l+1])); entries
+// with id < 0 are padding.  Writes min(top_n, distinct) records to d_out and the count to *d_count.
+int ensure_wrrf_scratch(anrag_index *idx, int64_t n_entries);
+void free_wrrf_scratch(anrag_index *idx);
+int launch_wrrf(anrag_index *idx, hipStream_t st, const int64_t *d_ids, const anrag_candidate *d_cands,
+                const int32_t *h_off, const double *h_weight, int32_t n_lists, double k, int32_t top_n,
+                anrag_candidate *d_out, int32_t *d_count);
 int launch_merge_candidates(anrag_index *idx, hipStream_t stream, const anrag_candidate *d_lists,
                             int32_t n_lists, int32_t k, anrag_candidate *d_out);
 

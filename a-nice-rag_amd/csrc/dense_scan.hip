@@ -12,6 +12,7 @@
 //   * the query slice of each lane lives in registers (CH float4), staged once per wave;
 //   * G-lane butterfly reduction, then the wave's register top-k (wave_topk.hpp);
 //   * per-workgroup LDS tree merge -> one sorted list per workgroup -> merge kernel (select.hip).
+//   * the 6-step lane reduction is DPP row ops (no LDS traffic in the streaming loop).
 #include "common.hpp"
 #include "wave_topk.hpp"
 
@@ -47,10 +48,6 @@ __device__ __forceinline__ float group_sum(float v) {
     if constexpr (G >= 32) v = dpp_add<0x142, 0xA>(v);
     if constexpr (G >= 64) v = dpp_add<0x143, 0xC>(v);
     return v;
-}
-
-__device__ __forceinline__ bool source_bit(const uint32_t *allow_lds, uint32_t s) {
-    return (allow_lds[s >> 5] >> (s & 31)) & 1u;
 }
 
 // G  lanes per row (64,32,16); dim % (4*G) == 0
@@ -109,7 +106,7 @@ __global__ __launch_bounds__(kScanThreads) void dense_scan_kernel(
             for (int c = 0; c < CH; ++c) acc = dot4(v[r][c], q[c], acc);
             acc = group_sum<G>(acc);
             bool ok = row[r] < n_rows;
-            if constexpr (FILTER) ok = ok && source_bit(lds_allow, sid[r]);
+            if constexpr (FILTER) ok = ok && source_ok(lds_allow, sid[r]);
             if constexpr (SCORES) {
                 if (leader && row[r] < n_rows) scores_out[row[r]] = ok ? acc : neg_inf<float>();
             } else {
@@ -152,7 +149,7 @@ __global__ __launch_bounds__(kScanThreads) void dense_scan_topk_generic_kernel(
         for (int c = lane; c < dim; c += kWave) acc = __builtin_fmaf(p[c], query[c], acc);
         acc = group_sum<kWave>(acc);  // total lands in lane 63
         bool ok = true;
-        if (filtered) ok = source_bit(lds_allow, src[row]);
+        if (filtered) ok = source_ok(lds_allow, src[row]);
         if (scores_out != nullptr && lane == kWave - 1) scores_out[row] = ok ? acc : neg_inf<float>();
         if (k > 0) top.offer_lanes(lane == kWave - 1 && ok && top.admits(acc, (uint32_t)row), acc, (uint32_t)row);
     }
@@ -162,52 +159,6 @@ __global__ __launch_bounds__(kScanThreads) void dense_scan_topk_generic_kernel(
             blk_score[blockIdx.x * kListLen + lane] = top.s;
             blk_row[blockIdx.x * kListLen + lane] = top.r;
         }
-    }
-}
-
-// Block lists (fp32 score, local row) -> global top-k as anrag_candidate {fp64 score, doc id}.
-__global__ __launch_bounds__(256) void dense_final_merge_kernel(const float *__restrict__ blk_score,
-                                                                const uint32_t *__restrict__ blk_row,
-                                                                int32_t n_lists, int32_t k,
-                                                                const int64_t *__restrict__ doc_of_row,
-                                                                int64_t doc_base,
-                                                                anrag_candidate *__restrict__ out) {
-    constexpr int W = 4;
-    __shared__ float lds_s[W * kListLen];
-    __shared__ uint32_t lds_r[W * kListLen];
-    const int lane = lane_id(), wave = threadIdx.x / kWave;
-    WaveTopK<float> top;
-    top.init(k);
-    // pass A: the heads of this wave's lists (lane <-> list), one coalesced-ish load
-    for (int l0 = wave * kWave; l0 < n_lists; l0 += W * kWave) {
-        const int list = l0 + lane;
-        const bool have = list < n_lists;
-        const float hs = have ? blk_score[list * kListLen] : neg_inf<float>();
-        const uint32_t hr = have ? blk_row[list * kListLen] : kNoRow;
-        top.offer_lanes(have && top.admits(hs, hr), hs, hr);
-        // pass B: a list whose head is still inside the top-k may hold more winners
-        unsigned long long m = __ballot(have && hr != kNoRow && !beats(top.thr_s, top.thr_r, hs, hr));
-        while (m) {
-            const int l = __builtin_ctzll(m);
-            m &= m - 1;
-            const int li = l0 + l;
-            const float es = blk_score[li * kListLen + lane];  // lane i <- entry i, 256 B coalesced
-            const uint32_t er = blk_row[li * kListLen + lane];
-            for (int i = 1; i < k; ++i) {
-                const float cs = read_lane(es, i);
-                const uint32_t cr = read_lane(er, i);
-                if (!top.admits(cs, cr)) break;
-                top.insert(cs, cr);
-            }
-        }
-    }
-    block_merge(top, lds_s, lds_r, W);
-    if (wave == 0 && lane < k) {
-        anrag_candidate c;
-        c.score = (double)top.s;
-        c.doc = top.r == kNoRow ? -1 : (doc_of_row ? doc_of_row[top.r] : doc_base + (int64_t)top.r);
-        if (top.r == kNoRow) c.score = -__builtin_huge_val();
-        out[lane] = c;
     }
 }
 
@@ -277,12 +228,9 @@ int launch_dense_topk(anrag_index *idx, hipStream_t st, const float *d_query, in
                                                                           d_scores_out);
         ANRAG_HIP(hipGetLastError());
     }
-    if (k > 0) {
-        LaunchTimer t(idx, ANRAG_KERNEL_SELECT, st);
-        dense_final_merge_kernel<<<1, 256, 0, st>>>(idx->d_blk_score_f32, idx->d_blk_row_a, grid, k, idx->d_dense_doc,
-                                                    idx->dense_doc_base, d_out);
-        ANRAG_HIP(hipGetLastError());
-    }
+    if (k > 0)
+        return launch_merge_block_lists_f32(idx, st, idx->d_blk_score_f32, idx->d_blk_row_a, grid, k, idx->d_dense_doc,
+                                            idx->dense_doc_base, d_out);
     return ANRAG_OK;
 }
 

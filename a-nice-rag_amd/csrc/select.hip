@@ -1,12 +1,80 @@
-// K4 -- selection over candidate records.
+// K4 -- selection over candidate lists.
 //
+//  * merge_block_lists_kernel<S>: the per-workgroup sorted lists K1 / K3 leave in HBM
+//    ([n_lists][64] score + local row) -> the shard's top-k as anrag_candidate {fp64 score, doc id}.
+//    One workgroup, lane <-> list, round j offers every still-live list's j-th entry: a list drops
+//    out at its first loser (it is sorted), so the number of dependent HBM round trips is the
+//    largest number of winners any single list holds (+1), not k and not n_lists.
 //  * merge_candidates_kernel: n_lists sorted lists of k anrag_candidate records (the RCCL
 //    all-gather receive buffer of the sharded path) -> global top-k by
-//    (score desc, doc asc).  Replicated on every rank, latency-bound, one workgroup.
+//    (score desc, doc asc).  Replicated on every rank, latency-bound, one wavefront.
 #include "common.hpp"
+#include "wave_topk.hpp"
 
 namespace anrag {
 
+template <typename S>
+__global__ __launch_bounds__(256) void merge_block_lists_kernel(const S *__restrict__ blk_score,
+                                                                const uint32_t *__restrict__ blk_row,
+                                                                int32_t n_lists, int32_t k,
+                                                                const int64_t *__restrict__ doc_of_row,
+                                                                int64_t doc_base, anrag_candidate *__restrict__ out) {
+    constexpr int W = 4;
+    __shared__ S lds_s[W * kListLen];
+    __shared__ uint32_t lds_r[W * kListLen];
+    const int lane = lane_id(), wave = threadIdx.x / kWave;
+    WaveTopK<S> top;
+    top.init(k);
+    for (int l0 = wave * kWave; l0 < n_lists; l0 += W * kWave) {
+        const int list = l0 + lane;
+        bool live = list < n_lists;
+        const S *ps = blk_score + (int64_t)(live ? list : 0) * kListLen;
+        const uint32_t *pr = blk_row + (int64_t)(live ? list : 0) * kListLen;
+        S cs = live ? ps[0] : neg_inf<S>();
+        uint32_t cr = live ? pr[0] : kNoRow;
+        for (int j = 0; j < k; ++j) {
+            // next round's entries are in flight while this round is merged
+            const bool more = live && (j + 1 < k);
+            const S ns = more ? ps[j + 1] : neg_inf<S>();
+            const uint32_t nr = more ? pr[j + 1] : kNoRow;
+            const bool cand = live && cr != kNoRow && top.admits(cs, cr);
+            if (__ballot(cand) == 0) break;
+            top.offer_lanes(cand, cs, cr);
+            // still inside the top-k after everybody's insertions?  otherwise the list is exhausted
+            live = cand && !beats(top.thr_s, top.thr_r, cs, cr);
+            cs = ns;
+            cr = nr;
+        }
+    }
+    block_merge(top, lds_s, lds_r, W);
+    if (wave == 0 && lane < k) {
+        anrag_candidate c;
+        const bool empty = top.r == kNoRow;
+        c.score = empty ? -__builtin_huge_val() : (double)top.s;
+        c.doc = empty ? -1 : (doc_of_row ? doc_of_row[top.r] : doc_base + (int64_t)top.r);
+        out[lane] = c;
+    }
+}
+
+int launch_merge_block_lists_f32(anrag_index *idx, hipStream_t st, const float *blk_score, const uint32_t *blk_row,
+                                 int32_t n_lists, int32_t k, const int64_t *doc_of_row, int64_t doc_base,
+                                 anrag_candidate *d_out) {
+    LaunchTimer t(idx, ANRAG_KERNEL_SELECT, st);
+    merge_block_lists_kernel<float><<<1, 256, 0, st>>>(blk_score, blk_row, n_lists, k, doc_of_row, doc_base, d_out);
+    ANRAG_HIP(hipGetLastError());
+    return ANRAG_OK;
+}
+
+int launch_merge_block_lists_f64(anrag_index *idx, hipStream_t st, const double *blk_score, const uint32_t *blk_row,
+                                 int32_t n_lists, int32_t k, const int64_t *doc_of_row, int64_t doc_base,
+                                 anrag_candidate *d_out) {
+    LaunchTimer t(idx, ANRAG_KERNEL_SELECT, st);
+    merge_block_lists_kernel<double><<<1, 256, 0, st>>>(blk_score, blk_row, n_lists, k, doc_of_row, doc_base, d_out);
+    ANRAG_HIP(hipGetLastError());
+    return ANRAG_OK;
+}
+
+// ------------------------------------------------------------------ cross-shard merge
 // Same register top-k as wave_topk.hpp but keyed on (fp64 score, int64 doc).
 struct DocTopK {
     double s;

@@ -24,6 +24,11 @@ __device__ __forceinline__ bool beats(S s, uint32_t r, S ts, uint32_t tr) {
     return s > ts || (s == ts && r < tr);
 }
 
+// allow bitmap (staged in LDS): bit s of word s/32 = rows with source id s pass the filter
+__device__ __forceinline__ bool source_ok(const uint32_t *allow_lds, uint32_t s) {
+    return (allow_lds[s >> 5] >> (s & 31)) & 1u;
+}
+
 __device__ __forceinline__ int lane_id() { return threadIdx.x & (kWave - 1); }
 
 // Wave-uniform read of one lane's value (v_readlane_b32: SGPR result).

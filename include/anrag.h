@@ -53,6 +53,8 @@ extern "C" {
  * lane of a 64-wide wavefront).  Larger k (retrieval_eval.py:142-143 uses 12000)
  * takes the score-array + radix-sort path; both are exact. */
 #define ANRAG_FUSED_K_MAX 64
+/* Most ranked lists one fusion call takes (the reference fuses at most 4 dense models + BM25). */
+#define ANRAG_WRRF_MAX_LISTS 16
 
 /* Candidate record exchanged between shards (RCCL all-gather payload) and
  * consumed by anrag_merge_candidates_device: 16 bytes, score widened to fp64
@@ -184,6 +186,17 @@ int anrag_hybrid_search(anrag_index *idx, const float *query, const int32_t *ter
                         int32_t n_bm25_sources, int64_t *out_id, double *out_score,
                         int32_t *out_count);
 
+/* Same, operands in HBM, nothing syncs the host: d_out receives min(top_n,
+ * distinct ids) records in fused order, *d_count that number.  Back-to-back
+ * queries pipeline: BM25 of query i+1 (secondary stream) runs under the dense
+ * scan of query i+1 once the fusion of query i has released its input slots. */
+int anrag_hybrid_search_device(anrag_index *idx, const float *d_query, const int32_t *d_term_ids,
+                               int32_t n_terms, int32_t similarity_k, double w_dense,
+                               double w_bm25, double wrrf_k, int32_t top_n,
+                               const uint32_t *d_allow_dense_bits,
+                               const uint32_t *d_allow_bm25_bits, anrag_candidate *d_out,
+                               int32_t *d_count);
+
 /* ------------------------------------------------------------------ sharded merge
  * After an all-gather of every shard's k candidates: merge n_lists sorted lists of
  * k records each into the global top-k (score desc, doc asc -- row order is
@@ -194,7 +207,8 @@ int anrag_merge_candidates_device(anrag_index *idx, const anrag_candidate *d_lis
 /* WRRF over two device candidate lists (dense, bm25) -> top_n on the device. */
 int anrag_wrrf_device(anrag_index *idx, const anrag_candidate *d_dense, int32_t n_dense,
                       const anrag_candidate *d_bm25, int32_t n_bm25, double w_dense,
-                      double w_bm25, double k, int32_t top_n, anrag_candidate *d_out);
+                      double w_bm25, double k, int32_t top_n, anrag_candidate *d_out,
+                      int32_t *d_count);
 
 /* ------------------------------------------------------------------ device memory helpers
  * (so a pure-ctypes caller can stage operands without torch) */
