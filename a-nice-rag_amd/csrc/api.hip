@@ -507,6 +507,24 @@ int anrag_wrrf_device(anrag_index *idx, const anrag_candidate *d_dense, int32_t 
 
 // ------------------------------------------------------------------ fused hybrid query
 // dense on `primary`, BM25 on `secondary`, WRRF on `primary` after the join; nothing syncs the host.
+static int legs_enqueue(anrag_index *idx, bool use_dense, bool use_bm25, const float *d_query,
+                        const int32_t *d_terms, int32_t n_terms, int32_t k, const uint32_t *d_allow_dense,
+                        const uint32_t *d_allow_bm25, anrag_candidate *dense_out, anrag_candidate *bm25_out) {
+    hipStream_t P = idx->primary, S = idx->secondary;
+    int rc;
+    if (use_bm25) {
+        // S starts after everything already queued on P (e.g. the previous query's fusion reading bm25_out)
+        ANRAG_HIP(hipEventRecord(idx->ev_fork, P));
+        ANRAG_HIP(hipStreamWaitEvent(S, idx->ev_fork, 0));
+        if ((rc = launch_bm25(idx, S, d_terms, n_terms, k, d_allow_bm25, bm25_out, nullptr))) return rc;
+        ANRAG_HIP(hipEventRecord(idx->ev_join, S));
+    }
+    if (use_dense)
+        if ((rc = launch_dense_topk(idx, P, d_query, k, d_allow_dense, dense_out, nullptr))) return rc;
+    if (use_bm25) ANRAG_HIP(hipStreamWaitEvent(P, idx->ev_join, 0));
+    return ANRAG_OK;
+}
+
 static int hybrid_enqueue(anrag_index *idx, const float *d_query, const int32_t *d_terms, int32_t n_terms,
                           int32_t similarity_k, double w_dense, double w_bm25, double wrrf_k, int32_t top_n,
                           const uint32_t *d_allow_dense, const uint32_t *d_allow_bm25, anrag_candidate *d_out,
@@ -514,19 +532,10 @@ static int hybrid_enqueue(anrag_index *idx, const float *d_query, const int32_t 
     const bool use_bm25 = idx->d_post_doc != nullptr && n_terms > 0 && w_bm25 > 0.0;
     const bool use_dense = idx->d_emb != nullptr && w_dense > 0.0;
     ANRAG_REQUIRE(use_dense || use_bm25, "hybrid search with neither a dense nor a BM25 leg");
-    hipStream_t P = idx->primary, S = idx->secondary;
     anrag_candidate *dense_out = idx->d_cand_a, *bm25_out = idx->d_cand_a + (use_dense ? similarity_k : 0);
-    int rc;
-    if (use_bm25) {
-        // S must not overwrite its slot while the previous query's fusion (on P) may still read it
-        ANRAG_HIP(hipEventRecord(idx->ev_fork, P));
-        ANRAG_HIP(hipStreamWaitEvent(S, idx->ev_fork, 0));
-        if ((rc = launch_bm25(idx, S, d_terms, n_terms, similarity_k, d_allow_bm25, bm25_out, nullptr))) return rc;
-        ANRAG_HIP(hipEventRecord(idx->ev_join, S));
-    }
-    if (use_dense)
-        if ((rc = launch_dense_topk(idx, P, d_query, similarity_k, d_allow_dense, dense_out, nullptr))) return rc;
-    if (use_bm25) ANRAG_HIP(hipStreamWaitEvent(P, idx->ev_join, 0));
+    int rc = legs_enqueue(idx, use_dense, use_bm25, d_query, d_terms, n_terms, similarity_k, d_allow_dense,
+                          d_allow_bm25, dense_out, bm25_out);
+    if (rc) return rc;
     int32_t off[3] = {0, 0, 0};
     double w[2] = {0, 0};
     int n_lists = 0;
@@ -540,7 +549,19 @@ static int hybrid_enqueue(anrag_index *idx, const float *d_query, const int32_t 
         off[n_lists + 1] = off[n_lists] + similarity_k;
         ++n_lists;
     }
-    return launch_wrrf(idx, P, nullptr, idx->d_cand_a, off, w, n_lists, wrrf_k, top_n, d_out, d_count);
+    return launch_wrrf(idx, idx->primary, nullptr, idx->d_cand_a, off, w, n_lists, wrrf_k, top_n, d_out, d_count);
+}
+
+int anrag_hybrid_candidates_device(anrag_index *idx, const float *d_query, const int32_t *d_term_ids, int32_t n_terms,
+                                   int32_t k, const uint32_t *d_allow_dense_bits, const uint32_t *d_allow_bm25_bits,
+                                   anrag_candidate *d_out) {
+    ANRAG_ENTER(idx);
+    ANRAG_REQUIRE(d_query && d_out, "NULL operand");
+    ANRAG_REQUIRE(idx->d_emb != nullptr && idx->d_post_doc != nullptr, "needs both a dense and a BM25 shard");
+    ANRAG_REQUIRE(n_terms >= 0 && (n_terms == 0 || d_term_ids), "bad term list");
+    ANRAG_REQUIRE(k > 0 && k <= ANRAG_FUSED_K_MAX, "1 <= k <= %d", ANRAG_FUSED_K_MAX);
+    return legs_enqueue(idx, true, true, d_query, d_term_ids, n_terms, k, d_allow_dense_bits, d_allow_bm25_bits, d_out,
+                        d_out + k);
 }
 
 int anrag_hybrid_search_device(anrag_index *idx, const float *d_query, const int32_t *d_term_ids, int32_t n_terms,
@@ -602,12 +623,13 @@ int anrag_hybrid_search(anrag_index *idx, const float *query, const int32_t *ter
 
 // ------------------------------------------------------------------ sharded merge
 int anrag_merge_candidates_device(anrag_index *idx, const anrag_candidate *d_lists, int32_t n_lists, int32_t k,
-                                  anrag_candidate *d_out) {
+                                  int64_t list_stride, anrag_candidate *d_out) {
     ANRAG_ENTER(idx);
     ANRAG_REQUIRE(d_lists && d_out, "NULL operand");
     ANRAG_REQUIRE(n_lists > 0 && k > 0 && k <= ANRAG_FUSED_K_MAX, "need n_lists > 0 and 1 <= k <= %d",
                   ANRAG_FUSED_K_MAX);
-    return launch_merge_candidates(idx, idx->primary, d_lists, n_lists, k, d_out);
+    ANRAG_REQUIRE(list_stride >= k, "list_stride %lld < k", (long long)list_stride);
+    return launch_merge_candidates(idx, idx->primary, d_lists, n_lists, k, list_stride, d_out);
 }
 
 // ------------------------------------------------------------------ device memory helpers

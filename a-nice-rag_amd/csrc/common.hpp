@@ -159,6 +159,6 @@ int launch_wrrf(anrag_index *idx, hipStream_t st, const int64_t *d_ids, const an
                 const int32_t *h_off, const double *h_weight, int32_t n_lists, double k, int32_t top_n,
                 anrag_candidate *d_out, int32_t *d_count);
 int launch_merge_candidates(anrag_index *idx, hipStream_t stream, const anrag_candidate *d_lists,
-                            int32_t n_lists, int32_t k, anrag_candidate *d_out);
+                            int32_t n_lists, int32_t k, int64_t list_stride, anrag_candidate *d_out);
 
 }  // namespace anrag

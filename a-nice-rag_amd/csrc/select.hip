@@ -113,7 +113,7 @@ struct DocTopK {
 };
 
 __global__ __launch_bounds__(64) void merge_candidates_kernel(const anrag_candidate *__restrict__ lists,
-                                                              int32_t n_lists, int32_t k,
+                                                              int32_t n_lists, int32_t k, int64_t stride,
                                                               anrag_candidate *__restrict__ out) {
     const int lane = threadIdx.x;
     DocTopK top;
@@ -123,7 +123,7 @@ __global__ __launch_bounds__(64) void merge_candidates_kernel(const anrag_candid
         anrag_candidate c;
         c.score = -__builtin_huge_val();
         c.doc = -1;
-        if (lane < k) c = lists[(int64_t)li * k + lane];
+        if (lane < k) c = lists[(int64_t)li * stride + lane];
         for (int i = 0; i < k; ++i) {
             const double cs = __shfl(c.score, i);
             const long long cd = __shfl((long long)c.doc, i);
@@ -140,9 +140,9 @@ __global__ __launch_bounds__(64) void merge_candidates_kernel(const anrag_candid
 }
 
 int launch_merge_candidates(anrag_index *idx, hipStream_t st, const anrag_candidate *d_lists, int32_t n_lists,
-                            int32_t k, anrag_candidate *d_out) {
+                            int32_t k, int64_t list_stride, anrag_candidate *d_out) {
     LaunchTimer t(idx, ANRAG_KERNEL_SELECT, st);
-    merge_candidates_kernel<<<1, 64, 0, st>>>(d_lists, n_lists, k, d_out);
+    merge_candidates_kernel<<<1, 64, 0, st>>>(d_lists, n_lists, k, list_stride, d_out);
     ANRAG_HIP(hipGetLastError());
     return ANRAG_OK;
 }

@@ -117,17 +117,27 @@ class Index:
     # ------------------------------------------------------------------ BM25
     def bm25_load(self, indptr, post_doc, post_tf, idf, doc_len, avgdl: float, k1: float, b: float,
                   source_id=None, doc_id=None, doc_id_base: int = 0) -> None:
+        """Postings may be numpy arrays or (device address, count) tuples of int32 buffers already in HBM
+        (e.g. torch tensors); indptr / idf / doc_len are host arrays."""
         indptr = np.ascontiguousarray(indptr, dtype=np.int64)
-        post_doc = np.ascontiguousarray(post_doc, dtype=np.int32)
-        post_tf = np.ascontiguousarray(post_tf, dtype=np.int32)
         idf = np.ascontiguousarray(idf, dtype=np.float64)
         doc_len = np.ascontiguousarray(doc_len, dtype=np.int32)
         n_terms, n_docs = indptr.size - 1, doc_len.size
-        assert idf.size == n_terms and post_doc.size == post_tf.size == int(indptr[-1])
+
+        def as_ptr(a):
+            if isinstance(a, tuple):
+                addr, count = a
+                return None, int(addr), int(count)
+            arr = np.ascontiguousarray(a, dtype=np.int32)
+            return arr, arr.ctypes.data, int(arr.size)
+
+        keep_d, pd_addr, pd_n = as_ptr(post_doc)
+        keep_t, pt_addr, pt_n = as_ptr(post_tf)
+        assert idf.size == n_terms and pd_n == pt_n == int(indptr[-1])
         src = None if source_id is None else np.ascontiguousarray(source_id, dtype=np.uint16)
         doc = None if doc_id is None else np.ascontiguousarray(doc_id, dtype=np.int64)
-        nat.check(self._lib.anrag_bm25_load(self.handle, indptr.ctypes.data, n_terms, nat.ptr(post_doc),
-                                            nat.ptr(post_tf), idf.ctypes.data, doc_len.ctypes.data, n_docs,
+        nat.check(self._lib.anrag_bm25_load(self.handle, indptr.ctypes.data, n_terms, pd_addr or None,
+                                            pt_addr or None, idf.ctypes.data, doc_len.ctypes.data, n_docs,
                                             float(avgdl), float(k1), float(b), nat.ptr(src), nat.ptr(doc),
                                             int(doc_id_base)))
         self.n_docs = int(n_docs)

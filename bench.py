@@ -1,0 +1,305 @@
+#!/usr/bin/env python3
+"""Headline benchmark: hybrid retrieval queries/sec on a 1M x 768 corpus (BASELINE.json configs[2]).
+
+    python bench.py --gpus N --steps K --warmup W          (N = 1)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A step = ONE query at batch=1 through the whole hot path: dense dot-product scan + top-25, BM25
+term-at-a-time + top-25, weighted RRF (5:1, k=40), top-10 -- the body of the reference's
+`retrieve_documents` for one dense model + BM25 (src/query_rag_retrieval.py:197-220, :304-378).
+Inputs (corpus matrix, postings, queries, term ids) are resident in HBM before the timed region;
+queries are enqueued back to back with no host synchronisation in between.
+
+N > 1: the SAME 1M-row corpus row-sharded N ways (strong scaling, the metric's "1M x 768 corpus,
+1/2/4/8 MI355X"): per-rank legs, one RCCL all-gather of 2 x 25 candidate records per rank on a
+communication stream, replicated merge + fusion (a-nice-rag_amd/sharded.py).
+
+Prints ONE JSON line on rank 0 (fields: README of the build contract + `roofline` + `cpu_baseline`).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 measured copy)
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--warmup", type=int, default=40)
+    ap.add_argument("--rows", type=int, default=1_000_000, help="corpus rows (whole job)")
+    ap.add_argument("--dim", type=int, default=768)
+    ap.add_argument("--vocab", type=int, default=200_000)
+    ap.add_argument("--similarity-k", type=int, default=25)
+    ap.add_argument("--top-n", type=int, default=10)
+    ap.add_argument("--queries", type=int, default=64, help="distinct synthetic queries cycled through")
+    ap.add_argument("--workload", choices=["hybrid", "dense"], default="hybrid")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-queries", type=int, default=3, help="queries of the bounded CPU sample")
+    return ap.parse_args()
+
+
+def main():
+    args = parse_args()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+    if world != args.gpus and rank == 0:
+        print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: libanrag has no CPU path")
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+
+    from anrag import _native as nat
+    from anrag import synth
+    from anrag.index import Index
+    from anrag.sharded import HipShardEngine, ShardedSearcher, shard_bounds
+
+    K, TOPN = args.similarity_k, args.top_n
+    W_DENSE, W_BM25, WRRF_K = 5.0, 1.0, 40.0  # src/config.py:30-36, retrieval_eval.py:279
+    hybrid = args.workload == "hybrid"
+    lo, hi = shard_bounds(args.rows, world, rank)
+    n_local = hi - lo
+
+    # ------------------------------------------------------------------ synthetic shard, resident in HBM
+    t_build = time.time()
+    E = synth.dense_corpus(n_local, args.dim, 1234 + rank, device)
+    idx = Index(local_rank)
+    idx.dense_load((E.data_ptr(), n_local, args.dim), doc_id_base=lo)
+    # queries: planted next to rows of rank 0's shard, identical on every rank
+    Q, planted = synth.dense_queries(E, args.queries, 4321)
+    if world > 1:
+        dist.broadcast(Q, 0)
+    post = None
+    term_lists = [np.zeros(0, np.int32)] * args.queries
+    if hybrid:
+        post = synth.bm25_postings(n_local, args.vocab, 777 + rank, device)
+        df = post["df"].clone()
+        tot = torch.tensor([post["total_len"]], device=device, dtype=torch.int64)
+        if world > 1:  # GLOBAL statistics, replicated (sharded.py docstring)
+            dist.all_reduce(df)
+            dist.all_reduce(tot)
+        avgdl = int(tot.item()) / args.rows
+        idf = synth.bm25_idf(df.cpu().numpy(), args.rows)
+        idx.bm25_load(post["indptr"], (post["post_doc"].data_ptr(), post["post_doc"].numel()),
+                      (post["post_tf"].data_ptr(), post["post_tf"].numel()), idf, post["doc_len"], avgdl,
+                      synth.BM25_K1, synth.BM25_B, doc_id_base=lo)
+        term_lists = synth.bm25_queries(post, args.queries, 99) if rank == 0 else None
+        if world > 1:
+            box = [term_lists]
+            dist.broadcast_object_list(box, 0)
+            term_lists = box[0]
+    max_terms = max(1, max(len(t) for t in term_lists))
+    T = torch.full((args.queries, max_terms), -1, dtype=torch.int32, device=device)
+    for i, t in enumerate(term_lists):
+        if len(t):
+            T[i, : len(t)] = torch.from_numpy(np.asarray(t, dtype=np.int32)).to(device)
+    n_terms = [int(len(t)) for t in term_lists]
+    torch.cuda.synchronize()
+    build_s = time.time() - t_build
+
+    # ------------------------------------------------------------------ the step
+    lib = nat.load_library()
+    if world == 1:
+        out = torch.zeros((args.queries, TOPN, 2), dtype=torch.int64, device=device)
+        cnt = torch.zeros(args.queries, dtype=torch.int32, device=device)
+
+        def step(i):
+            qi = i % args.queries
+            if hybrid:
+                nat.check(lib.anrag_hybrid_search_device(
+                    idx.handle, Q[qi].data_ptr(), T[qi].data_ptr(), n_terms[qi], K, W_DENSE, W_BM25, WRRF_K, TOPN,
+                    None, None, out[qi].data_ptr(), cnt[qi:].data_ptr()))
+            else:
+                nat.check(lib.anrag_dense_search_device(idx.handle, Q[qi].data_ptr(), 1, TOPN, None,
+                                                        out[qi].data_ptr()))
+
+        def finish():
+            idx.sync()
+    else:
+        if not hybrid:
+            raise SystemExit("--workload dense is a single-GPU diagnostic")
+        engine = HipShardEngine(idx, device)
+        searcher = ShardedSearcher(engine, k=K, top_n=TOPN, w_dense=W_DENSE, w_bm25=W_BM25, wrrf_k=WRRF_K,
+                                   depth=4, device=device)
+
+        def step(i):
+            qi = i % args.queries
+            searcher.submit(Q[qi], T[qi], n_terms[qi])
+
+        def finish():
+            searcher.drain()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    finish()
+    idx.profile(True)
+    idx.profile_reset()
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    finish()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    scan_ms, scan_n = idx.profile_read(nat.KERNEL_DENSE_SCAN)
+    bm25_ms, bm25_n = idx.profile_read(nat.KERNEL_BM25)
+    sel_ms, sel_n = idx.profile_read(nat.KERNEL_SELECT)
+    wrrf_ms, wrrf_n = idx.profile_read(nat.KERNEL_WRRF)
+    idx.profile(False)
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ------------------------------------------------------------------ report (rank 0)
+    if rank == 0:
+        scan_avg_ms = scan_ms / max(scan_n, 1)
+        alg_bytes = n_local * args.dim * 4  # N*D*4 per query (this rank's rows)
+        achieved = alg_bytes / (scan_avg_ms * 1e-3) / 1e9 if scan_n else 0.0
+        traffic = None
+        pmc = os.path.join(REPO, "profiles", "pmc_dense_scan.json")
+        if os.path.exists(pmc):
+            try:
+                with open(pmc) as f:
+                    rec = json.load(f)
+                if rec.get("rows") == n_local and rec.get("dim") == args.dim:
+                    traffic = rec.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "queries/sec, hybrid (dense + BM25) RRF top-10 at batch=1, 1M x 768 corpus",
+            "value": args.steps / elapsed,
+            "unit": "queries/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": ("C3: %d x %d hybrid (dense + BM25 CSR postings) RRF top-%d, batch=1" % (args.rows, args.dim, TOPN))
+                if hybrid else ("dense-only brute-force top-%d, %d x %d, batch=1" % (TOPN, args.rows, args.dim)),
+                "rows": args.rows, "dim": args.dim, "rows_per_gpu": n_local,
+                "postings_per_gpu": (int(post["post_doc"].numel()) if post else 0), "vocab": args.vocab if hybrid else 0,
+                "similarity_k": K, "top_n": TOPN, "wrrf_k": WRRF_K, "weights": [W_DENSE, W_BM25],
+                "sharding": "rows/%d + RCCL all-gather of per-shard top-k" % world if world > 1 else "none",
+                "bm25_arith": "f64",
+            },
+            "roofline": {
+                "kernel": "dense_scan_kernel (K1)", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": scan_avg_ms, "launches": scan_n,
+            },
+            "kernel_ms": {"dense_scan": scan_avg_ms, "bm25": bm25_ms / max(bm25_n, 1),
+                          "select_per_launch": sel_ms / max(sel_n, 1), "wrrf": wrrf_ms / max(wrrf_n, 1)},
+            "index_build_s": build_s,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args, E, Q, post, idf if hybrid else None,
+                                                avgdl if hybrid else None, term_lists, out, cnt, hybrid, K, TOPN,
+                                                (W_DENSE, W_BM25, WRRF_K))
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(args, E, Q, post, idf, avgdl, term_lists, gpu_out, gpu_cnt, hybrid, K, TOPN, fusion):
+    """The reference-shaped CPU path (oracle = port of src/search_engine.py) timed on this box's host
+    cores over a bounded sample of the same queries, and used as the parity check of the GPU results."""
+    import torch
+    from oracle import ref_bm25, ref_search
+
+    w_dense, w_bm25, wrrf_k = fusion
+    nq = max(1, min(args.cpu_queries, args.queries))
+    e_host = E.cpu().numpy()
+    q_host = Q[:nq].cpu().numpy()
+    if hybrid:
+        post_doc = post["post_doc"].cpu().numpy()
+        post_tf = post["post_tf"].cpu().numpy()
+    rows = list(e_host)  # the reference keeps one ndarray per DataFrame row (database_manager.py:49)
+    t_ref = t_pre = 0.0
+    parity_ok = True
+    max_dscore = 0.0
+    for qi in range(nq):
+        t0 = time.perf_counter()
+        emb = np.stack(rows)  # search_engine.py:80 -- re-materialised on every query
+        sims = np.dot(q_host[qi].reshape(1, -1), emb.T).flatten()
+        top = ref_search.numpy_topk_idiom(sims, K)
+        dense_list = top.tolist()
+        t_stack_path = time.perf_counter() - t0
+        t1 = time.perf_counter()
+        sims2 = np.dot(q_host[qi].reshape(1, -1), e_host.T).flatten()
+        ref_search.numpy_topk_idiom(sims2, K)
+        t_dense_pre = time.perf_counter() - t1
+        t2 = time.perf_counter()
+        if hybrid:
+            scores = ref_bm25.csr_get_scores(post["indptr"], post_doc, post_tf, idf, post["doc_len"], avgdl,
+                                             1.7, 0.83, term_lists[qi].tolist())
+            bm_list = ref_search.canonical_topk(scores, K).tolist()
+            fused = ref_search.weighted_reciprocal_rank_fusion(
+                [(dense_list, "dense"), (bm_list, "BM25")], {"dense": w_dense, "BM25": w_bm25}, int(wrrf_k))[:TOPN]
+            want_ids = [i for i, _ in fused]
+        else:
+            want_ids = dense_list[:TOPN]
+        t_rest = time.perf_counter() - t2
+        t_ref += t_stack_path + t_rest
+        t_pre += t_dense_pre + t_rest
+        # parity of the GPU's answer for this query (full-size check, same inputs)
+        n = int(gpu_cnt[qi].item()) if hybrid else TOPN
+        rec = gpu_out[qi, :n].cpu().numpy()
+        got_ids = rec[:, 1].tolist()
+        if got_ids != want_ids:
+            # dense near-ties may legitimately reorder within 1e-4; compare as sets then
+            parity_ok = parity_ok and (set(got_ids) == set(want_ids))
+        if hybrid:
+            got_s = rec[:, 0].copy().view(np.float64)
+            max_dscore = max(max_dscore, float(np.max(np.abs(got_s - np.array([s for _, s in fused])))) if n else 0.0)
+    try:
+        from threadpoolctl import threadpool_info
+
+        blas_threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+    except Exception:
+        blas_threads = os.cpu_count() or 1
+    return {
+        "value": nq / t_ref, "unit": "queries/s", "cores": blas_threads, "kind": "port",
+        "sample": "%d of the %d benchmark queries, full %d x %d corpus on the host: reference-shaped path "
+                  "(np.stack of per-row arrays per query as search_engine.py:80 does, np.dot, argpartition; CSR "
+                  "restatement of BM25Okapi.get_scores; Python WRRF)" % (nq, args.queries, args.rows, args.dim),
+        "value_prestacked": nq / t_pre,
+        "note_prestacked": "same sample with the corpus matrix stacked once up front (removes the reference's "
+                           "per-query np.stack)",
+        "gpu_results_match_cpu": bool(parity_ok), "max_abs_fused_score_diff": max_dscore,
+    }
+
+
+if __name__ == "__main__":
+    main()

@@ -201,9 +201,19 @@ int anrag_hybrid_search_device(anrag_index *idx, const float *d_query, const int
  * After an all-gather of every shard's k candidates: merge n_lists sorted lists of
  * k records each into the global top-k (score desc, doc asc -- row order is
  * shard-local, doc ids are global and ascend with rows under row sharding).
+ * List l starts at d_lists + l * list_stride records (list_stride >= k).
  * All device pointers; enqueued on the primary stream. */
 int anrag_merge_candidates_device(anrag_index *idx, const anrag_candidate *d_lists,
-                                  int32_t n_lists, int32_t k, anrag_candidate *d_out);
+                                  int32_t n_lists, int32_t k, int64_t list_stride,
+                                  anrag_candidate *d_out);
+/* Both legs of a hybrid query on this shard, no fusion: d_out[0..k) = dense
+ * candidates, d_out[k..2k) = BM25 candidates -- one rank's all-gather payload.
+ * Dense runs on the primary stream, BM25 on the secondary; the primary stream
+ * waits for both before anything queued after this call. */
+int anrag_hybrid_candidates_device(anrag_index *idx, const float *d_query,
+                                   const int32_t *d_term_ids, int32_t n_terms, int32_t k,
+                                   const uint32_t *d_allow_dense_bits,
+                                   const uint32_t *d_allow_bm25_bits, anrag_candidate *d_out);
 /* WRRF over two device candidate lists (dense, bm25) -> top_n on the device. */
 int anrag_wrrf_device(anrag_index *idx, const anrag_candidate *d_dense, int32_t n_dense,
                       const anrag_candidate *d_bm25, int32_t n_bm25, double w_dense,

@@ -146,15 +146,22 @@ class CsrBM25:
         return [self.term_id.get(q, -1) for q in query]
 
     def get_scores(self, query: Sequence[str]) -> np.ndarray:
-        score = np.zeros(self.n_docs)
-        k1, b = self.k1, self.b
-        for t in self.term_ids(query):
-            if t < 0:
-                continue
-            w = self.idf[t] or 0
-            lo, hi = self.indptr[t], self.indptr[t + 1]
-            docs = self.post_doc[lo:hi]
-            f = self.post_tf[lo:hi].astype(np.int64)
-            dl = self.doc_len[docs].astype(np.int64)
-            score[docs] += w * (f * (k1 + 1) / (f + k1 * (1 - b + b * dl / self.avgdl)))
-        return score
+        return csr_get_scores(self.indptr, self.post_doc, self.post_tf, self.idf, self.doc_len, self.avgdl,
+                              self.k1, self.b, self.term_ids(query))
+
+
+def csr_get_scores(indptr, post_doc, post_tf, idf, doc_len, avgdl, k1, b, term_ids) -> np.ndarray:
+    """`BM25Okapi.get_scores` over raw CSR arrays (term ids in query order, negative = unknown token).
+    Same operator order as the dict form: only documents that hold the term receive a non-zero addend,
+    and adding the reference's `idf * 0.0` to the others changes nothing."""
+    score = np.zeros(len(doc_len))
+    for t in term_ids:
+        if t < 0:
+            continue
+        w = idf[t] or 0
+        lo, hi = indptr[t], indptr[t + 1]
+        docs = post_doc[lo:hi]
+        f = post_tf[lo:hi].astype(np.int64)
+        dl = doc_len[docs].astype(np.int64)
+        score[docs] += w * (f * (k1 + 1) / (f + k1 * (1 - b + b * dl / avgdl)))
+    return score
