@@ -45,7 +45,7 @@ _SIGNATURES = {
     "anrag_device_count": [C.POINTER(C.c_int)],
     "anrag_index_create": [C.c_int, C.POINTER(_p)],
     "anrag_index_destroy": [_p],
-    "anrag_index_set_streams": [_p, _p, _p],
+    "anrag_index_set_streams": [_p, _p, _p, _p],
     "anrag_index_sync": [_p],
     "anrag_dense_load": [_p, _p, _i64, _i32, _p, _p, _i64],
     "anrag_dense_search": [_p, _p, _i32, _i32, _p, _i32, _p, _p, _p],
@@ -65,7 +65,7 @@ _SIGNATURES = {
     "anrag_device_free": [_p, _p],
     "anrag_copy_to_device": [_p, _p, _p, _i64],
     "anrag_copy_to_host": [_p, _p, _p, _i64],
-    "anrag_profile_enable": [_p, C.c_int],
+    "anrag_profile_enable": [_p, C.c_uint32],
     "anrag_profile_reset": [_p],
     "anrag_profile_read": [_p, C.c_int, C.POINTER(_f64), C.POINTER(_i64)],
     "anrag_index_info": [_p, C.POINTER(_i64), C.POINTER(_i32), C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)],

@@ -32,14 +32,14 @@ static hipEvent_t take_event(anrag_index *idx) {
 }
 
 LaunchTimer::LaunchTimer(anrag_index *i, int k, hipStream_t s) : idx(i), stream(s), kernel(k) {
-    if (!idx->profiling) return;
+    if (!idx->profiling || !((idx->profile_mask >> k) & 1u)) return;
     start = take_event(idx);
     stop = take_event(idx);
     if (start) (void)hipEventRecord(start, stream);
 }
 
 LaunchTimer::~LaunchTimer() {
-    if (!idx->profiling || !start || !stop) return;
+    if (!start || !stop) return;
     (void)hipEventRecord(stop, stream);
     idx->spans.push_back(ProfSpan{kernel, start, stop});
 }
@@ -194,8 +194,15 @@ int anrag_index_create(int device, anrag_index **out) {
     DeviceGuard g(device);
     hipError_t e = hipStreamCreateWithFlags(&idx->own_primary, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&idx->own_secondary, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&idx->own_fusion, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&idx->ev_fork, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&idx->ev_join, hipEventDisableTiming);
+    for (int b = 0; b < 2 && e == hipSuccess; ++b) {
+        e = hipEventCreateWithFlags(&idx->ev_scan[b], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&idx->ev_bm25[b], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&idx->ev_merged[b], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&idx->ev_fused[b], hipEventDisableTiming);
+    }
     if (e != hipSuccess) {
         set_error("stream/event creation failed: %s", hipGetErrorString(e));
         delete idx;
@@ -203,6 +210,7 @@ int anrag_index_create(int device, anrag_index **out) {
     }
     idx->primary = idx->own_primary;
     idx->secondary = idx->own_secondary;
+    idx->fusion = idx->own_fusion;
     *out = idx;
     return ANRAG_OK;
 }
@@ -222,6 +230,7 @@ int anrag_index_destroy(anrag_index *idx) {
         DeviceGuard g(idx->device);
         (void)hipStreamSynchronize(idx->primary);
         (void)hipStreamSynchronize(idx->secondary);
+        (void)hipStreamSynchronize(idx->fusion);
         (void)drain_profile(idx);
         free_dense(idx);
         free_bm25(idx);
@@ -235,6 +244,12 @@ int anrag_index_destroy(anrag_index *idx) {
         for (hipEvent_t e : idx->event_pool) (void)hipEventDestroy(e);
         if (idx->ev_fork) (void)hipEventDestroy(idx->ev_fork);
         if (idx->ev_join) (void)hipEventDestroy(idx->ev_join);
+        for (int b = 0; b < 2; ++b) {
+            hipEvent_t evs[] = {idx->ev_scan[b], idx->ev_bm25[b], idx->ev_merged[b], idx->ev_fused[b]};
+            for (hipEvent_t ev : evs)
+                if (ev) (void)hipEventDestroy(ev);
+        }
+        if (idx->own_fusion) (void)hipStreamDestroy(idx->own_fusion);
         if (idx->own_primary) (void)hipStreamDestroy(idx->own_primary);
         if (idx->own_secondary) (void)hipStreamDestroy(idx->own_secondary);
     }
@@ -242,26 +257,41 @@ int anrag_index_destroy(anrag_index *idx) {
     return ANRAG_OK;
 }
 
-int anrag_index_set_streams(anrag_index *idx, void *primary, void *secondary) {
-    ANRAG_ENTER(idx);
+static int sync_all(anrag_index *idx) {
     ANRAG_HIP(hipStreamSynchronize(idx->primary));
     ANRAG_HIP(hipStreamSynchronize(idx->secondary));
+    ANRAG_HIP(hipStreamSynchronize(idx->fusion));
+    idx->hyb_outstanding = false;
+    return ANRAG_OK;
+}
+
+// Entry points outside the hybrid pipeline reuse its buffers: let an outstanding pipeline drain first.
+static int settle_pipeline(anrag_index *idx) {
+    if (!idx->hyb_outstanding) return ANRAG_OK;
+    return sync_all(idx);
+}
+
+int anrag_index_set_streams(anrag_index *idx, void *primary, void *secondary, void *fusion) {
+    ANRAG_ENTER(idx);
+    int rc = sync_all(idx);
+    if (rc) return rc;
     idx->primary = primary ? (hipStream_t)primary : idx->own_primary;
     idx->secondary = secondary ? (hipStream_t)secondary : idx->own_secondary;
+    idx->fusion = fusion ? (hipStream_t)fusion : idx->own_fusion;
+    idx->hyb_seq = 0;
     return ANRAG_OK;
 }
 
 int anrag_index_sync(anrag_index *idx) {
     ANRAG_ENTER(idx);
-    ANRAG_HIP(hipStreamSynchronize(idx->primary));
-    ANRAG_HIP(hipStreamSynchronize(idx->secondary));
-    return ANRAG_OK;
+    return sync_all(idx);
 }
 
 // ------------------------------------------------------------------ dense
 int anrag_dense_load(anrag_index *idx, const float *embeddings, int64_t n_rows, int32_t dim,
                      const uint16_t *source_id, const int64_t *doc_id, int64_t doc_id_base) {
     ANRAG_ENTER(idx);
+    if (int rc0 = settle_pipeline(idx)) return rc0;
     ANRAG_REQUIRE(embeddings != nullptr, "embeddings is NULL");
     ANRAG_REQUIRE(n_rows > 0 && n_rows < 0xFFFFFFFFll, "n_rows %lld out of range (1 .. 2^32-2 per shard)",
                   (long long)n_rows);
@@ -284,8 +314,8 @@ int anrag_dense_load(anrag_index *idx, const float *embeddings, int64_t n_rows, 
     }
     idx->dense_doc_base = doc_id_base;
     if (!idx->d_blk_score_f32) {
-        if ((rc = dev_alloc(idx, &idx->d_blk_score_f32, (int64_t)kMaxScanBlocks * kListLen))) return rc;
-        if ((rc = dev_alloc(idx, &idx->d_blk_row_a, (int64_t)kMaxScanBlocks * kListLen))) return rc;
+        if ((rc = dev_alloc(idx, &idx->d_blk_score_f32, (int64_t)2 * kMaxScanBlocks * kListLen))) return rc;
+        if ((rc = dev_alloc(idx, &idx->d_blk_row_a, (int64_t)2 * kMaxScanBlocks * kListLen))) return rc;
     }
     if ((rc = ensure_query_buffer(idx, (int64_t)64 * dim))) return rc;
     return ANRAG_OK;
@@ -294,6 +324,8 @@ int anrag_dense_load(anrag_index *idx, const float *embeddings, int64_t n_rows, 
 int anrag_dense_search_device(anrag_index *idx, const float *d_queries, int32_t n_queries, int32_t k,
                               const uint32_t *d_allow_bits, anrag_candidate *d_out) {
     ANRAG_ENTER(idx);
+    if (int rc0 = settle_pipeline(idx)) return rc0;
+    if (int rc0 = settle_pipeline(idx)) return rc0;
     ANRAG_REQUIRE(idx->d_emb != nullptr, "dense search before anrag_dense_load");
     ANRAG_REQUIRE(d_queries && d_out, "NULL operand");
     ANRAG_REQUIRE(n_queries > 0, "n_queries must be positive");
@@ -308,6 +340,7 @@ int anrag_dense_search_device(anrag_index *idx, const float *d_queries, int32_t 
 
 int anrag_dense_scores(anrag_index *idx, const float *query, float *out_scores) {
     ANRAG_ENTER(idx);
+    if (int rc0 = settle_pipeline(idx)) return rc0;
     ANRAG_REQUIRE(idx->d_emb != nullptr, "dense scores before anrag_dense_load");
     ANRAG_REQUIRE(query && out_scores, "NULL operand");
     int rc;
@@ -369,6 +402,7 @@ int anrag_bm25_load(anrag_index *idx, const int64_t *indptr, int64_t n_terms, co
                     const int32_t *post_tf, const double *idf, const int32_t *doc_len, int64_t n_docs, double avgdl,
                     double k1, double b, const uint16_t *source_id, const int64_t *doc_id, int64_t doc_id_base) {
     ANRAG_ENTER(idx);
+    if (int rc0 = settle_pipeline(idx)) return rc0;
     int rc = ensure_common_workspace(idx);
     if (rc) return rc;
     return bm25_load(idx, indptr, n_terms, post_doc, post_tf, idf, doc_len, n_docs, avgdl, k1, b, source_id, doc_id,
@@ -386,6 +420,8 @@ static int stage_terms(anrag_index *idx, hipStream_t st, const int32_t *term_ids
 int anrag_bm25_search_device(anrag_index *idx, const int32_t *d_term_ids, int32_t n_terms, int32_t k,
                              const uint32_t *d_allow_bits, anrag_candidate *d_out) {
     ANRAG_ENTER(idx);
+    if (int rc0 = settle_pipeline(idx)) return rc0;
+    if (int rc0 = settle_pipeline(idx)) return rc0;
     ANRAG_REQUIRE(idx->d_post_doc != nullptr, "BM25 search before anrag_bm25_load");
     ANRAG_REQUIRE(d_out && (n_terms == 0 || d_term_ids), "NULL operand");
     ANRAG_REQUIRE(n_terms >= 0, "n_terms must be >= 0");
@@ -425,6 +461,7 @@ int anrag_bm25_search(anrag_index *idx, const int32_t *term_ids, int32_t n_terms
 
 int anrag_bm25_scores(anrag_index *idx, const int32_t *term_ids, int32_t n_terms, double *out_scores) {
     ANRAG_ENTER(idx);
+    if (int rc0 = settle_pipeline(idx)) return rc0;
     ANRAG_REQUIRE(idx->d_post_doc != nullptr, "BM25 scores before anrag_bm25_load");
     ANRAG_REQUIRE(out_scores != nullptr, "NULL operand");
     hipStream_t st = idx->primary;
@@ -446,6 +483,7 @@ int anrag_bm25_scores(anrag_index *idx, const int32_t *term_ids, int32_t n_terms
 int anrag_wrrf(anrag_index *idx, const int64_t *ids, const int32_t *list_len, const double *weight, int32_t n_lists,
                double k, int32_t top_n, int64_t *out_id, double *out_score, int32_t *out_count) {
     ANRAG_ENTER(idx);
+    if (int rc0 = settle_pipeline(idx)) return rc0;
     ANRAG_REQUIRE(list_len && weight && out_id && out_score && out_count, "NULL operand");
     ANRAG_REQUIRE(n_lists >= 1 && n_lists <= ANRAG_WRRF_MAX_LISTS, "n_lists %d out of range [1, %d]", n_lists,
                   ANRAG_WRRF_MAX_LISTS);
@@ -488,11 +526,12 @@ int anrag_wrrf_device(anrag_index *idx, const anrag_candidate *d_dense, int32_t 
                       const anrag_candidate *d_bm25, int32_t n_bm25, double w_dense, double w_bm25, double k,
                       int32_t top_n, anrag_candidate *d_out, int32_t *d_count) {
     ANRAG_ENTER(idx);
+    if (int rc0 = settle_pipeline(idx)) return rc0;
     ANRAG_REQUIRE(d_dense && d_out && d_count, "NULL operand");
     ANRAG_REQUIRE(n_dense >= 0 && n_bm25 >= 0 && n_dense + n_bm25 > 0 && n_dense + n_bm25 <= 1024,
                   "need 0 < n_dense + n_bm25 <= 1024");
     ANRAG_REQUIRE(top_n > 0, "top_n must be positive");
-    hipStream_t st = idx->primary;
+    hipStream_t st = idx->fusion;
     int rc;
     if ((rc = ensure_common_workspace(idx))) return rc;
     // the two lists have to be contiguous for the kernel: stage them in the index's candidate buffer
@@ -507,49 +546,66 @@ int anrag_wrrf_device(anrag_index *idx, const anrag_candidate *d_dense, int32_t 
 
 // ------------------------------------------------------------------ fused hybrid query
 // dense on `primary`, BM25 on `secondary`, WRRF on `primary` after the join; nothing syncs the host.
-static int legs_enqueue(anrag_index *idx, bool use_dense, bool use_bm25, const float *d_query,
-                        const int32_t *d_terms, int32_t n_terms, int32_t k, const uint32_t *d_allow_dense,
-                        const uint32_t *d_allow_bm25, anrag_candidate *dense_out, anrag_candidate *bm25_out) {
-    hipStream_t P = idx->primary, S = idx->secondary;
-    int rc;
-    if (use_bm25) {
-        // S starts after everything already queued on P (e.g. the previous query's fusion reading bm25_out)
-        ANRAG_HIP(hipEventRecord(idx->ev_fork, P));
-        ANRAG_HIP(hipStreamWaitEvent(S, idx->ev_fork, 0));
-        if ((rc = launch_bm25(idx, S, d_terms, n_terms, k, d_allow_bm25, bm25_out, nullptr))) return rc;
-        ANRAG_HIP(hipEventRecord(idx->ev_join, S));
-    }
-    if (use_dense)
-        if ((rc = launch_dense_topk(idx, P, d_query, k, d_allow_dense, dense_out, nullptr))) return rc;
-    if (use_bm25) ANRAG_HIP(hipStreamWaitEvent(P, idx->ev_join, 0));
-    return ANRAG_OK;
-}
+// One hybrid query through the three-stream pipeline (no host sync):
+//   primary    scan(b)                                               -> block lists, set b
+//   secondary  BM25 + partition-list merge                           -> cand[b][k..2k)
+//   fusion     dense block-list merge -> cand[b][0..k); then `tail`  (WRRF, or the copy-out of both lists)
+// b = sequence number & 1.  Back-to-back queries keep the scans adjacent on `primary`; everything else of
+// query i runs under the scan of query i+1.
+enum HybridTail { kTailFuse, kTailCandidates };
 
-static int hybrid_enqueue(anrag_index *idx, const float *d_query, const int32_t *d_terms, int32_t n_terms,
-                          int32_t similarity_k, double w_dense, double w_bm25, double wrrf_k, int32_t top_n,
+static int hybrid_enqueue(anrag_index *idx, HybridTail tail, const float *d_query, const int32_t *d_terms,
+                          int32_t n_terms, int32_t k, double w_dense, double w_bm25, double wrrf_k, int32_t top_n,
                           const uint32_t *d_allow_dense, const uint32_t *d_allow_bm25, anrag_candidate *d_out,
                           int32_t *d_count) {
-    const bool use_bm25 = idx->d_post_doc != nullptr && n_terms > 0 && w_bm25 > 0.0;
-    const bool use_dense = idx->d_emb != nullptr && w_dense > 0.0;
+    const bool use_bm25 = idx->d_post_doc != nullptr && n_terms > 0 && (tail == kTailCandidates || w_bm25 > 0.0);
+    const bool use_dense = idx->d_emb != nullptr && (tail == kTailCandidates || w_dense > 0.0);
     ANRAG_REQUIRE(use_dense || use_bm25, "hybrid search with neither a dense nor a BM25 leg");
-    anrag_candidate *dense_out = idx->d_cand_a, *bm25_out = idx->d_cand_a + (use_dense ? similarity_k : 0);
-    int rc = legs_enqueue(idx, use_dense, use_bm25, d_query, d_terms, n_terms, similarity_k, d_allow_dense,
-                          d_allow_bm25, dense_out, bm25_out);
-    if (rc) return rc;
-    int32_t off[3] = {0, 0, 0};
-    double w[2] = {0, 0};
-    int n_lists = 0;
+    hipStream_t P = idx->primary, S = idx->secondary, F = idx->fusion;
+    const int b = (int)(idx->hyb_seq & 1);
+    const bool reuse = idx->hyb_seq >= 2;
+    idx->hyb_seq++;
+    idx->hyb_outstanding = true;
+    anrag_candidate *cand = idx->d_cand_a + (int64_t)b * 2 * ANRAG_FUSED_K_MAX;
+    anrag_candidate *dense_out = cand, *bm25_out = cand + k;
+    int rc, grid = 0;
     if (use_dense) {
-        w[n_lists] = w_dense;
-        off[n_lists + 1] = off[n_lists] + similarity_k;
-        ++n_lists;
+        if (reuse) ANRAG_HIP(hipStreamWaitEvent(P, idx->ev_merged[b], 0));  // block-list set b is free again
+        if ((rc = launch_dense_scan(idx, P, d_query, k, d_allow_dense, nullptr, b, &grid))) return rc;
+        ANRAG_HIP(hipEventRecord(idx->ev_scan[b], P));
     }
     if (use_bm25) {
-        w[n_lists] = w_bm25;
-        off[n_lists + 1] = off[n_lists] + similarity_k;
-        ++n_lists;
+        if (reuse) ANRAG_HIP(hipStreamWaitEvent(S, idx->ev_fused[b], 0));  // cand[b] is free again
+        if ((rc = launch_bm25(idx, S, d_terms, n_terms, k, d_allow_bm25, bm25_out, nullptr))) return rc;
+        ANRAG_HIP(hipEventRecord(idx->ev_bm25[b], S));
     }
-    return launch_wrrf(idx, idx->primary, nullptr, idx->d_cand_a, off, w, n_lists, wrrf_k, top_n, d_out, d_count);
+    if (use_dense) {
+        ANRAG_HIP(hipStreamWaitEvent(F, idx->ev_scan[b], 0));
+        if ((rc = launch_dense_merge(idx, F, grid, k, b, dense_out))) return rc;
+    }
+    ANRAG_HIP(hipEventRecord(idx->ev_merged[b], F));
+    if (use_bm25) ANRAG_HIP(hipStreamWaitEvent(F, idx->ev_bm25[b], 0));
+    if (tail == kTailFuse) {
+        int32_t off[3] = {0, 0, 0};
+        double w[2] = {0, 0};
+        int n_lists = 0;
+        const anrag_candidate *first = use_dense ? dense_out : bm25_out;
+        if (use_dense) {
+            w[n_lists] = w_dense;
+            off[n_lists + 1] = off[n_lists] + k;
+            ++n_lists;
+        }
+        if (use_bm25) {
+            w[n_lists] = w_bm25;
+            off[n_lists + 1] = off[n_lists] + k;
+            ++n_lists;
+        }
+        if ((rc = launch_wrrf(idx, F, nullptr, first, off, w, n_lists, wrrf_k, top_n, d_out, d_count))) return rc;
+    } else {
+        ANRAG_HIP(hipMemcpyAsync(d_out, cand, (size_t)2 * k * sizeof(anrag_candidate), hipMemcpyDeviceToDevice, F));
+    }
+    ANRAG_HIP(hipEventRecord(idx->ev_fused[b], F));
+    return ANRAG_OK;
 }
 
 int anrag_hybrid_candidates_device(anrag_index *idx, const float *d_query, const int32_t *d_term_ids, int32_t n_terms,
@@ -558,10 +614,10 @@ int anrag_hybrid_candidates_device(anrag_index *idx, const float *d_query, const
     ANRAG_ENTER(idx);
     ANRAG_REQUIRE(d_query && d_out, "NULL operand");
     ANRAG_REQUIRE(idx->d_emb != nullptr && idx->d_post_doc != nullptr, "needs both a dense and a BM25 shard");
-    ANRAG_REQUIRE(n_terms >= 0 && (n_terms == 0 || d_term_ids), "bad term list");
+    ANRAG_REQUIRE(n_terms > 0 && d_term_ids, "needs at least one term id (use the dense path otherwise)");
     ANRAG_REQUIRE(k > 0 && k <= ANRAG_FUSED_K_MAX, "1 <= k <= %d", ANRAG_FUSED_K_MAX);
-    return legs_enqueue(idx, true, true, d_query, d_term_ids, n_terms, k, d_allow_dense_bits, d_allow_bm25_bits, d_out,
-                        d_out + k);
+    return hybrid_enqueue(idx, kTailCandidates, d_query, d_term_ids, n_terms, k, 1.0, 1.0, 0.0, 0, d_allow_dense_bits,
+                          d_allow_bm25_bits, d_out, nullptr);
 }
 
 int anrag_hybrid_search_device(anrag_index *idx, const float *d_query, const int32_t *d_term_ids, int32_t n_terms,
@@ -573,7 +629,7 @@ int anrag_hybrid_search_device(anrag_index *idx, const float *d_query, const int
     ANRAG_REQUIRE(similarity_k > 0 && similarity_k <= ANRAG_FUSED_K_MAX, "fused hybrid serves 1 <= similarity_k <= %d",
                   ANRAG_FUSED_K_MAX);
     ANRAG_REQUIRE(top_n > 0 && top_n <= 2 * ANRAG_FUSED_K_MAX, "top_n %d out of range", top_n);
-    return hybrid_enqueue(idx, d_query, d_term_ids, n_terms, similarity_k, w_dense, w_bm25, wrrf_k, top_n,
+    return hybrid_enqueue(idx, kTailFuse, d_query, d_term_ids, n_terms, similarity_k, w_dense, w_bm25, wrrf_k, top_n,
                           d_allow_dense_bits, d_allow_bm25_bits, d_out, d_count);
 }
 
@@ -588,30 +644,31 @@ int anrag_hybrid_search(anrag_index *idx, const float *query, const int32_t *ter
     ANRAG_REQUIRE(top_n > 0 && top_n <= 2 * ANRAG_FUSED_K_MAX, "top_n %d out of range", top_n);
     ANRAG_REQUIRE(!(allow_dense && !idx->d_dense_src) && !(allow_bm25 && !idx->d_bm25_src),
                   "a source filter needs source ids");
-    hipStream_t P = idx->primary;
     int rc;
+    if ((rc = settle_pipeline(idx))) return rc;  // the staging buffers below are single
+    hipStream_t P = idx->primary, S = idx->secondary, F = idx->fusion;
     if ((rc = ensure_common_workspace(idx))) return rc;
     if ((rc = ensure_wrrf_scratch(idx, 4096))) return rc;
     char *pin = static_cast<char *>(idx->h_pinned);
     const uint32_t *d_ad = nullptr, *d_ab = nullptr;
     if ((rc = stage_allow(idx, P, allow_dense, n_dense_sources, idx->d_allow_a, reinterpret_cast<uint32_t *>(pin), &d_ad)))
         return rc;
-    if ((rc = stage_allow(idx, P, allow_bm25, n_bm25_sources, idx->d_allow_b, reinterpret_cast<uint32_t *>(pin + 8192),
+    if ((rc = stage_allow(idx, S, allow_bm25, n_bm25_sources, idx->d_allow_b, reinterpret_cast<uint32_t *>(pin + 8192),
                           &d_ab)))
         return rc;
     if (idx->d_emb && w_dense > 0.0) {
         ANRAG_REQUIRE(query != nullptr, "query is NULL");
         ANRAG_HIP(hipMemcpyAsync(idx->d_query, query, (size_t)idx->dim * sizeof(float), hipMemcpyHostToDevice, P));
     }
-    if ((rc = stage_terms(idx, P, term_ids, n_terms))) return rc;
-    if ((rc = hybrid_enqueue(idx, idx->d_query, idx->d_terms, n_terms, similarity_k, w_dense, w_bm25, wrrf_k, top_n,
-                             d_ad, d_ab, idx->d_w_out, idx->d_w_count)))
+    if ((rc = stage_terms(idx, S, term_ids, n_terms))) return rc;
+    if ((rc = hybrid_enqueue(idx, kTailFuse, idx->d_query, idx->d_terms, n_terms, similarity_k, w_dense, w_bm25, wrrf_k,
+                             top_n, d_ad, d_ab, idx->d_w_out, idx->d_w_count)))
         return rc;
     anrag_candidate *h_cand = reinterpret_cast<anrag_candidate *>(pin + 16384);
     int32_t *h_cnt = reinterpret_cast<int32_t *>(pin + 16384 + 4096);
-    ANRAG_HIP(hipMemcpyAsync(h_cand, idx->d_w_out, (size_t)top_n * sizeof(anrag_candidate), hipMemcpyDeviceToHost, P));
-    ANRAG_HIP(hipMemcpyAsync(h_cnt, idx->d_w_count, sizeof(int32_t), hipMemcpyDeviceToHost, P));
-    ANRAG_HIP(hipStreamSynchronize(P));
+    ANRAG_HIP(hipMemcpyAsync(h_cand, idx->d_w_out, (size_t)top_n * sizeof(anrag_candidate), hipMemcpyDeviceToHost, F));
+    ANRAG_HIP(hipMemcpyAsync(h_cnt, idx->d_w_count, sizeof(int32_t), hipMemcpyDeviceToHost, F));
+    if ((rc = sync_all(idx))) return rc;
     const int32_t cnt = std::min(*h_cnt, top_n);
     for (int32_t i = 0; i < cnt; ++i) {
         out_id[i] = h_cand[i].doc;
@@ -625,11 +682,12 @@ int anrag_hybrid_search(anrag_index *idx, const float *query, const int32_t *ter
 int anrag_merge_candidates_device(anrag_index *idx, const anrag_candidate *d_lists, int32_t n_lists, int32_t k,
                                   int64_t list_stride, anrag_candidate *d_out) {
     ANRAG_ENTER(idx);
+    if (int rc0 = settle_pipeline(idx)) return rc0;
     ANRAG_REQUIRE(d_lists && d_out, "NULL operand");
     ANRAG_REQUIRE(n_lists > 0 && k > 0 && k <= ANRAG_FUSED_K_MAX, "need n_lists > 0 and 1 <= k <= %d",
                   ANRAG_FUSED_K_MAX);
     ANRAG_REQUIRE(list_stride >= k, "list_stride %lld < k", (long long)list_stride);
-    return launch_merge_candidates(idx, idx->primary, d_lists, n_lists, k, list_stride, d_out);
+    return launch_merge_candidates(idx, idx->fusion, d_lists, n_lists, k, list_stride, d_out);
 }
 
 // ------------------------------------------------------------------ device memory helpers
@@ -663,13 +721,14 @@ int anrag_copy_to_host(anrag_index *idx, void *h_dst, const void *d_src, int64_t
 }
 
 // ------------------------------------------------------------------ measurement
-int anrag_profile_enable(anrag_index *idx, int on) {
+int anrag_profile_enable(anrag_index *idx, uint32_t kernel_mask) {
     ANRAG_ENTER(idx);
-    if (!on) {
+    if (!kernel_mask) {
         int rc = drain_profile(idx);
         if (rc) return rc;
     }
-    idx->profiling = on != 0;
+    idx->profiling = kernel_mask != 0;
+    idx->profile_mask = kernel_mask;
     return ANRAG_OK;
 }
 

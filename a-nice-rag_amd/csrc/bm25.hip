@@ -31,10 +31,11 @@
 
 namespace anrag {
 
-constexpr int kBm25Threads = 256;
-constexpr int kBm25Waves = kBm25Threads / kWave;
+constexpr int kBm25Threads = 1024;  // 16 waves: with one partition per CU the postings of a term are one
+constexpr int kBm25Waves = kBm25Threads / kWave;  // round trip (<= kPostPerThread loads per thread, all in flight)
 constexpr int kMaxPartDocs = 4096;
-constexpr int kFrequentDf = 2048;
+constexpr int kPostPerThread = kMaxPartDocs / kBm25Threads;  // a term has at most one posting per document
+constexpr int kFrequentDf = kBm25Threads;  // rarer terms: the whole list is one load per thread, range-checked
 constexpr int kTermBatch = 128;
 
 // ------------------------------------------------------------------ load-time kernels
@@ -82,7 +83,7 @@ __global__ __launch_bounds__(kBm25Threads) void bm25_kernel(
     __shared__ double slice[kMaxPartDocs];
     __shared__ double t_w[kTermBatch];
     __shared__ int64_t t_base[kTermBatch];
-    __shared__ int32_t t_begin[kTermBatch], t_end[kTermBatch], t_scan[kTermBatch];
+    __shared__ int32_t t_begin[kTermBatch], t_end[kTermBatch];
     __shared__ double lds_s[kBm25Waves * kListLen];
     __shared__ uint32_t lds_r[kBm25Waves * kListLen];
     __shared__ uint32_t lds_allow[FILTER ? 2048 : 1];
@@ -97,6 +98,24 @@ __global__ __launch_bounds__(kBm25Threads) void bm25_kernel(
     if constexpr (FILTER)
         for (int i = tid; i < 2048; i += kBm25Threads) lds_allow[i] = allow_bits[i];
 
+    // One term = at most kPostPerThread postings per thread (a partition holds <= 4096 documents and a term
+    // names a document once).  The postings of term j+1 are fetched into registers BEFORE the barrier that
+    // closes term j, so the dependent HBM round trips of consecutive terms overlap.
+    struct Fetched {
+        int32_t d[kPostPerThread];
+        double v[kPostPerThread];
+    };
+    auto fetch = [&](int32_t j, Fetched &f) {
+        const int64_t base = t_base[j];
+        const int32_t a = t_begin[j], e = t_end[j];
+#pragma unroll
+        for (int u = 0; u < kPostPerThread; ++u) {
+            const int32_t i = a + tid + u * kBm25Threads;
+            const bool in = i < e;
+            f.d[u] = in ? post_doc[base + i] : -1;
+            f.v[u] = in ? impact[base + i] : 0.0;
+        }
+    };
     for (int32_t b0 = 0; b0 < n_terms; b0 += kTermBatch) {
         const int32_t nb = n_terms - b0 < kTermBatch ? n_terms - b0 : kTermBatch;
         __syncthreads();  // slice zeroed / previous batch's table no longer read
@@ -104,7 +123,7 @@ __global__ __launch_bounds__(kBm25Threads) void bm25_kernel(
             const int32_t t = terms[b0 + tid];
             double w = 0.0;
             int64_t base = 0;
-            int32_t a = 0, e = 0, scan = 0;
+            int32_t a = 0, e = 0;
             if (t >= 0 && (int64_t)t < n_vocab) {
                 w = idf[t];  // `(idf.get(q) or 0)`: an idf of exactly 0 contributes nothing
                 base = indptr[t];
@@ -113,35 +132,28 @@ __global__ __launch_bounds__(kBm25Threads) void bm25_kernel(
                     a = part_ptr[(int64_t)slot * (n_parts + 1) + part];
                     e = part_ptr[(int64_t)slot * (n_parts + 1) + part + 1];
                 } else {
-                    e = (int32_t)(indptr[t + 1] - base);
-                    scan = 1;
+                    e = (int32_t)(indptr[t + 1] - base);  // < kFrequentDf: scanned whole
                 }
+                if (w == 0.0) e = a;
             }
             t_w[tid] = w;
             t_base[tid] = base;
             t_begin[tid] = a;
             t_end[tid] = e;
-            t_scan[tid] = scan;
         }
         __syncthreads();
+        Fetched cur, nxt;
+        fetch(0, cur);
         for (int32_t j = 0; j < nb; ++j) {
+            if (j + 1 < nb) fetch(j + 1, nxt);
             const double w = t_w[j];
-            if (w != 0.0) {
-                const int64_t base = t_base[j];
-                const int32_t e = t_end[j];
-                if (t_scan[j]) {
-                    for (int32_t i = tid; i < e; i += kBm25Threads) {
-                        const int64_t d = post_doc[base + i];
-                        if (d >= lo && d < hi) slice[d - lo] = slice[d - lo] + w * impact[base + i];
-                    }
-                } else {
-                    for (int32_t i = t_begin[j] + tid; i < e; i += kBm25Threads) {
-                        const int32_t d = post_doc[base + i] - (int32_t)lo;
-                        slice[d] = slice[d] + w * impact[base + i];
-                    }
-                }
+#pragma unroll
+            for (int u = 0; u < kPostPerThread; ++u) {
+                const int64_t d = cur.d[u];
+                if (d >= lo && d < hi) slice[d - lo] = slice[d - lo] + w * cur.v[u];
             }
             __syncthreads();  // term j is complete before term j+1 may touch the same document
+            cur = nxt;
         }
     }
     if (n_terms == 0) __syncthreads();

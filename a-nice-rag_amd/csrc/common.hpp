@@ -15,7 +15,7 @@ namespace anrag {
 
 constexpr int kWave = 64;            // CDNA wavefront
 constexpr int kListLen = 64;         // one top-k slot per lane (ANRAG_FUSED_K_MAX)
-constexpr int kScanThreads = 1024;   // 16 waves: one scan workgroup per CU
+constexpr int kScanThreads = 256;    // 4 waves: one scan workgroup per CU (sweep: profiles/r01_scan_config_sweep.txt)
 constexpr int kScanWaves = kScanThreads / kWave;
 constexpr int kMaxScanBlocks = 256;  // one per CU; also bounds the final merge fan-in
 constexpr uint32_t kNoRow = 0xFFFFFFFFu;
@@ -52,9 +52,18 @@ struct anrag_index {
     int device = 0;
     int n_cus = 256;
     std::mutex mu;
-    hipStream_t own_primary = nullptr, own_secondary = nullptr;
-    hipStream_t primary = nullptr, secondary = nullptr;
+    // primary: dense scans.  secondary: BM25 + its list merge.  fusion: dense list merge + WRRF (and, in the
+    // sharded path, the caller's collectives).  A hybrid query touches all three and never syncs the host.
+    hipStream_t own_primary = nullptr, own_secondary = nullptr, own_fusion = nullptr;
+    hipStream_t primary = nullptr, secondary = nullptr, fusion = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    // hybrid pipeline, double-buffered on (query sequence number & 1)
+    hipEvent_t ev_scan[2] = {nullptr, nullptr};    // scan of buffer b finished (primary)
+    hipEvent_t ev_bm25[2] = {nullptr, nullptr};    // BM25 candidates of buffer b ready (secondary)
+    hipEvent_t ev_merged[2] = {nullptr, nullptr};  // block lists of buffer b consumed (fusion)
+    hipEvent_t ev_fused[2] = {nullptr, nullptr};   // candidate slots of buffer b consumed (fusion)
+    uint64_t hyb_seq = 0;
+    bool hyb_outstanding = false;
 
     // ---- dense shard: row-major fp32, rows 16-byte aligned when dim % 4 == 0
     float *d_emb = nullptr;
@@ -79,7 +88,7 @@ struct anrag_index {
     double bm25_k1 = 0, bm25_b = 0, bm25_avgdl = 0;
 
     // ---- workspaces (sized at load; reused by every query on the stream that owns them)
-    float *d_blk_score_f32 = nullptr;  // [kMaxScanBlocks][kListLen]
+    float *d_blk_score_f32 = nullptr;  // [2][kMaxScanBlocks][kListLen]  (two sets: hybrid pipeline)
     uint32_t *d_blk_row_a = nullptr;
     double *d_blk_score_f64 = nullptr;  // BM25 per-partition lists
     uint32_t *d_blk_row_b = nullptr;
@@ -110,6 +119,7 @@ struct anrag_index {
 
     // ---- measurement
     bool profiling = false;
+    uint32_t profile_mask = 0xFFFFFFFFu;  // bit i: time kernel id i
     std::vector<anrag::ProfSpan> spans;
     std::vector<hipEvent_t> event_pool;
     double prof_ms[ANRAG_KERNEL_COUNT] = {0};
@@ -131,6 +141,11 @@ struct LaunchTimer {
 int drain_profile(anrag_index *idx);
 
 // ---- kernel launchers (each enqueues on `stream`, never syncs)
+// scan only: leaves one sorted list per workgroup in block-list set `set`; *out_grid = number of lists
+int launch_dense_scan(anrag_index *idx, hipStream_t stream, const float *d_query, int32_t k,
+                      const uint32_t *d_allow_bits, float *d_scores_out, int set, int *out_grid);
+int launch_dense_merge(anrag_index *idx, hipStream_t stream, int n_lists, int32_t k, int set, anrag_candidate *d_out);
+// scan + merge on one stream (set 0)
 int launch_dense_topk(anrag_index *idx, hipStream_t stream, const float *d_query, int32_t k,
                       const uint32_t *d_allow_bits, anrag_candidate *d_out, float *d_scores_out);
 // k > ANRAG_FUSED_K_MAX: score array + radix sort (select.hip); host operands, syncs.

@@ -8,7 +8,9 @@
 //   * G lanes share one row (G = 64 when D % 256 == 0: a whole wave reads 1 KiB of one row per
 //     global_load_dwordx4; D = 384 uses G = 32, i.e. two rows per wave-load, 512 B each);
 //   * a wave keeps R row-groups in flight per iteration (R*CH dwordx4 loads per lane issued
-//     before the first use), 16 waves per CU, one workgroup per CU striding the matrix;
+//     before the first use); ONE 4-wave workgroup per CU strides the matrix: 4 waves x 12 KiB =
+//     48 KiB in flight per CU measured best on MI355X (7.0 TB/s at 1M x 768; 8/16 waves or deeper
+//     unrolls = 96-192 KiB in flight lose 3-6 %, and they starve co-running kernels: profiles/);
 //   * the query slice of each lane lives in registers (CH float4), staged once per wave;
 //   * G-lane butterfly reduction, then the wave's register top-k (wave_topk.hpp);
 //   * per-workgroup LDS tree merge -> one sorted list per workgroup -> merge kernel (select.hip).
@@ -55,15 +57,16 @@ __device__ __forceinline__ float group_sum(float v) {
 // R  row-groups in flight per wave iteration
 // FILTER  rows carry a source id and an allow bitmap is applied before selection
 // SCORES  write every row's score (large-k path / anrag_dense_scores) instead of selecting
-template <int G, int CH, int R, bool FILTER, bool SCORES>
-__global__ __launch_bounds__(kScanThreads) void dense_scan_kernel(
+template <int G, int CH, int R, bool FILTER, bool SCORES, int THREADS = kScanThreads>
+__global__ __launch_bounds__(THREADS) void dense_scan_kernel(
     const float *__restrict__ emb, const float *__restrict__ query, int64_t n_rows, int32_t dim, int32_t k,
     const uint16_t *__restrict__ src, const uint32_t *__restrict__ allow_bits, float *__restrict__ blk_score,
     uint32_t *__restrict__ blk_row, float *__restrict__ scores_out) {
     constexpr int GROUPS = kWave / G;  // rows per wave-load
     constexpr int RW = GROUPS * R;     // rows per wave iteration
-    __shared__ float lds_s[kScanWaves * kListLen];
-    __shared__ uint32_t lds_r[kScanWaves * kListLen];
+    constexpr int WAVES = THREADS / kWave;
+    __shared__ float lds_s[WAVES * kListLen];
+    __shared__ uint32_t lds_r[WAVES * kListLen];
     __shared__ uint32_t lds_allow[FILTER ? 2048 : 1];  // 65536 source ids
 
     const int lane = lane_id();
@@ -71,7 +74,7 @@ __global__ __launch_bounds__(kScanThreads) void dense_scan_kernel(
     const int sub = lane % G, grp = lane / G;
     const bool leader = sub == G - 1;
     if constexpr (FILTER) {
-        for (int i = threadIdx.x; i < 2048; i += kScanThreads) lds_allow[i] = allow_bits[i];
+        for (int i = threadIdx.x; i < 2048; i += THREADS) lds_allow[i] = allow_bits[i];
         __syncthreads();
     }
 
@@ -84,8 +87,8 @@ __global__ __launch_bounds__(kScanThreads) void dense_scan_kernel(
     WaveTopK<float> top;
     top.init(SCORES ? 1 : k);
 
-    const int64_t total_waves = (int64_t)gridDim.x * kScanWaves;
-    const int64_t gwave = (int64_t)blockIdx.x * kScanWaves + wave;
+    const int64_t total_waves = (int64_t)gridDim.x * WAVES;
+    const int64_t gwave = (int64_t)blockIdx.x * WAVES + wave;
     for (int64_t base = gwave * RW; base < n_rows; base += total_waves * RW) {
         f32x4 v[R][CH];
         int64_t row[R];
@@ -116,7 +119,7 @@ __global__ __launch_bounds__(kScanThreads) void dense_scan_kernel(
         }
     }
     if constexpr (!SCORES) {
-        block_merge(top, lds_s, lds_r, kScanWaves);
+        block_merge(top, lds_s, lds_r, WAVES);
         if (wave == 0) {
             blk_score[blockIdx.x * kListLen + lane] = top.s;
             blk_row[blockIdx.x * kListLen + lane] = top.r;
@@ -164,12 +167,11 @@ __global__ __launch_bounds__(kScanThreads) void dense_scan_topk_generic_kernel(
 
 template <int G, int CH>
 static void launch_scan(int grid, hipStream_t st, const anrag_index *idx, const float *q, int32_t k,
-                        const uint32_t *allow, float *scores_out) {
+                        const uint32_t *allow, float *scores_out, float *blk_s, uint32_t *blk_r) {
     constexpr int R = (CH >= 8) ? 2 : 4;
 #define ANRAG_SCAN(F, S)                                                                                     \
     dense_scan_kernel<G, CH, R, F, S><<<grid, kScanThreads, 0, st>>>(                                          \
-        idx->d_emb, q, idx->n_rows, idx->dim, k, idx->d_dense_src, allow, idx->d_blk_score_f32, idx->d_blk_row_a, \
-        scores_out)
+        idx->d_emb, q, idx->n_rows, idx->dim, k, idx->d_dense_src, allow, blk_s, blk_r, scores_out)
     if (scores_out) {
         if (allow) ANRAG_SCAN(true, true); else ANRAG_SCAN(false, true);
     } else {
@@ -178,9 +180,11 @@ static void launch_scan(int grid, hipStream_t st, const anrag_index *idx, const 
 #undef ANRAG_SCAN
 }
 
-int launch_dense_topk(anrag_index *idx, hipStream_t st, const float *d_query, int32_t k,
-                      const uint32_t *d_allow_bits, anrag_candidate *d_out, float *d_scores_out) {
+int launch_dense_scan(anrag_index *idx, hipStream_t st, const float *d_query, int32_t k,
+                      const uint32_t *d_allow_bits, float *d_scores_out, int set, int *out_grid) {
     const int64_t n = idx->n_rows;
+    float *blk_s = idx->d_blk_score_f32 + (int64_t)set * kMaxScanBlocks * kListLen;
+    uint32_t *blk_r = idx->d_blk_row_a + (int64_t)set * kMaxScanBlocks * kListLen;
     const int d = idx->dim;
     int grid = idx->n_cus < kMaxScanBlocks ? idx->n_cus : kMaxScanBlocks;
     {
@@ -194,28 +198,28 @@ int launch_dense_topk(anrag_index *idx, hipStream_t st, const float *d_query, in
         bool done = true;
         if (d % 256 == 0 && d / 256 <= 8) {
             switch (d / 256) {
-                case 1: launch_scan<64, 1>(grid, st, idx, d_query, k, allow, d_scores_out); break;
-                case 2: launch_scan<64, 2>(grid, st, idx, d_query, k, allow, d_scores_out); break;
-                case 3: launch_scan<64, 3>(grid, st, idx, d_query, k, allow, d_scores_out); break;
-                case 4: launch_scan<64, 4>(grid, st, idx, d_query, k, allow, d_scores_out); break;
-                case 6: launch_scan<64, 6>(grid, st, idx, d_query, k, allow, d_scores_out); break;
-                case 8: launch_scan<64, 8>(grid, st, idx, d_query, k, allow, d_scores_out); break;
+                case 1: launch_scan<64, 1>(grid, st, idx, d_query, k, allow, d_scores_out, blk_s, blk_r); break;
+                case 2: launch_scan<64, 2>(grid, st, idx, d_query, k, allow, d_scores_out, blk_s, blk_r); break;
+                case 3: launch_scan<64, 3>(grid, st, idx, d_query, k, allow, d_scores_out, blk_s, blk_r); break;
+                case 4: launch_scan<64, 4>(grid, st, idx, d_query, k, allow, d_scores_out, blk_s, blk_r); break;
+                case 6: launch_scan<64, 6>(grid, st, idx, d_query, k, allow, d_scores_out, blk_s, blk_r); break;
+                case 8: launch_scan<64, 8>(grid, st, idx, d_query, k, allow, d_scores_out, blk_s, blk_r); break;
                 default: done = false;
             }
         } else if (d % 128 == 0 && d / 128 <= 8) {
             switch (d / 128) {
-                case 1: launch_scan<32, 1>(grid, st, idx, d_query, k, allow, d_scores_out); break;
-                case 3: launch_scan<32, 3>(grid, st, idx, d_query, k, allow, d_scores_out); break;
-                case 5: launch_scan<32, 5>(grid, st, idx, d_query, k, allow, d_scores_out); break;
-                case 7: launch_scan<32, 7>(grid, st, idx, d_query, k, allow, d_scores_out); break;
+                case 1: launch_scan<32, 1>(grid, st, idx, d_query, k, allow, d_scores_out, blk_s, blk_r); break;
+                case 3: launch_scan<32, 3>(grid, st, idx, d_query, k, allow, d_scores_out, blk_s, blk_r); break;
+                case 5: launch_scan<32, 5>(grid, st, idx, d_query, k, allow, d_scores_out, blk_s, blk_r); break;
+                case 7: launch_scan<32, 7>(grid, st, idx, d_query, k, allow, d_scores_out, blk_s, blk_r); break;
                 default: done = false;
             }
         } else if (d % 64 == 0 && d / 64 <= 8) {
             switch (d / 64) {
-                case 1: launch_scan<16, 1>(grid, st, idx, d_query, k, allow, d_scores_out); break;
-                case 3: launch_scan<16, 3>(grid, st, idx, d_query, k, allow, d_scores_out); break;
-                case 5: launch_scan<16, 5>(grid, st, idx, d_query, k, allow, d_scores_out); break;
-                case 7: launch_scan<16, 7>(grid, st, idx, d_query, k, allow, d_scores_out); break;
+                case 1: launch_scan<16, 1>(grid, st, idx, d_query, k, allow, d_scores_out, blk_s, blk_r); break;
+                case 3: launch_scan<16, 3>(grid, st, idx, d_query, k, allow, d_scores_out, blk_s, blk_r); break;
+                case 5: launch_scan<16, 5>(grid, st, idx, d_query, k, allow, d_scores_out, blk_s, blk_r); break;
+                case 7: launch_scan<16, 7>(grid, st, idx, d_query, k, allow, d_scores_out, blk_s, blk_r); break;
                 default: done = false;
             }
         } else {
@@ -223,14 +227,26 @@ int launch_dense_topk(anrag_index *idx, hipStream_t st, const float *d_query, in
         }
         if (!done)
             dense_scan_topk_generic_kernel<<<grid, kScanThreads, 0, st>>>(idx->d_emb, d_query, n, d, k,
-                                                                          idx->d_dense_src, allow,
-                                                                          idx->d_blk_score_f32, idx->d_blk_row_a,
+                                                                          idx->d_dense_src, allow, blk_s, blk_r,
                                                                           d_scores_out);
         ANRAG_HIP(hipGetLastError());
     }
-    if (k > 0)
-        return launch_merge_block_lists_f32(idx, st, idx->d_blk_score_f32, idx->d_blk_row_a, grid, k, idx->d_dense_doc,
-                                            idx->dense_doc_base, d_out);
+    *out_grid = grid;
+    return ANRAG_OK;
+}
+
+int launch_dense_merge(anrag_index *idx, hipStream_t st, int n_lists, int32_t k, int set, anrag_candidate *d_out) {
+    return launch_merge_block_lists_f32(idx, st, idx->d_blk_score_f32 + (int64_t)set * kMaxScanBlocks * kListLen,
+                                        idx->d_blk_row_a + (int64_t)set * kMaxScanBlocks * kListLen, n_lists, k,
+                                        idx->d_dense_doc, idx->dense_doc_base, d_out);
+}
+
+int launch_dense_topk(anrag_index *idx, hipStream_t st, const float *d_query, int32_t k,
+                      const uint32_t *d_allow_bits, anrag_candidate *d_out, float *d_scores_out) {
+    int grid = 0;
+    int rc = launch_dense_scan(idx, st, d_query, k, d_allow_bits, d_scores_out, 0, &grid);
+    if (rc) return rc;
+    if (k > 0) return launch_dense_merge(idx, st, grid, k, 0, d_out);
     return ANRAG_OK;
 }
 

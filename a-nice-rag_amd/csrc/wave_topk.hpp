@@ -4,7 +4,8 @@
 // which is the build's deterministic reading of the reference's selection at
 // src/search_engine.py:83-87 / :233 / :236-243.  An empty slot is
 // (-inf, kNoRow): the minimum of that order, so real rows with score -inf or 0
-// still rank (the reference does not drop zero-score BM25 documents).
+// still rank (the reference does not drop zero-score BM25 documents).  All 64 lanes always hold the
+// wave's 64 best so far (only the first k are consumed): merges are bitonic networks over whole lists.
 // NaN never beats anything and is therefore never selected (documented gap:
 // numpy would rank NaN first).
 #pragma once
@@ -44,6 +45,43 @@ __device__ __forceinline__ double read_lane(double v, int l) {
     return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
 
+// ---- sorting networks over the 64 lanes (one (score,row) pair per lane, best first)
+// compare-exchange with lane ^ stride: keep the better of the pair when `keep_better`, else the worse
+template <typename S>
+__device__ __forceinline__ void cmp_exchange(S &s, uint32_t &r, int stride, bool keep_better) {
+    const S os = __shfl_xor(s, stride);
+    const uint32_t orow = __shfl_xor(r, stride);
+    const bool other_better = beats(os, orow, s, r);
+    if (other_better == keep_better) {
+        s = os;
+        r = orow;
+    }
+}
+
+// full bitonic sort, descending by (score desc, row asc): 21 compare-exchange stages
+template <typename S>
+__device__ __forceinline__ void bitonic_sort64(S &s, uint32_t &r) {
+    const int lane = threadIdx.x & (kWave - 1);
+#pragma unroll
+    for (int size = 2; size <= kWave; size <<= 1) {
+#pragma unroll
+        for (int stride = size >> 1; stride >= 1; stride >>= 1) {
+            const bool lower = (lane & stride) == 0;
+            const bool desc = (lane & size) == 0 || size == kWave;
+            cmp_exchange(s, r, stride, lower == desc);
+        }
+    }
+}
+
+// (s, r) holds a bitonic sequence (first descending, then ascending, or any rotation-free bitonic
+// shape produced by the max-with-reversed trick below): 6 stages sort it descending
+template <typename S>
+__device__ __forceinline__ void bitonic_merge64(S &s, uint32_t &r) {
+    const int lane = threadIdx.x & (kWave - 1);
+#pragma unroll
+    for (int stride = kWave >> 1; stride >= 1; stride >>= 1) cmp_exchange(s, r, stride, (lane & stride) == 0);
+}
+
 template <typename S>
 struct WaveTopK {
     S s;          // this lane's slot
@@ -77,26 +115,45 @@ struct WaveTopK {
         thr_r = read_lane(r, k - 1);
     }
 
-    // Offer one candidate per flagged lane (flag already includes admits()); wave-uniform loop.
-    __device__ __forceinline__ void offer_lanes(bool flag, S cs, uint32_t cr) {
-        unsigned long long m = __ballot(flag);
-        while (m) {
-            const int l = __builtin_ctzll(m);
-            m &= m - 1;
-            const S us = read_lane(cs, l);
-            const uint32_t ur = read_lane(cr, l);
-            if (admits(us, ur)) insert(us, ur);
+    // Keep the best 64 of {this list} U {another list sorted best-first whose entry 63-lane is (rs, rr)}:
+    // lane-wise max against the reversed list is a bitonic sequence holding exactly those 64.
+    __device__ __forceinline__ void merge_reversed(S rs, uint32_t rr) {
+        if (beats(rs, rr, s, r)) {
+            s = rs;
+            r = rr;
         }
+        bitonic_merge64(s, r);
+        thr_s = read_lane(s, k - 1);
+        thr_r = read_lane(r, k - 1);
     }
 
-    // Merge a sorted list that lives in LDS/global (uniform reads), stopping at the first loser.
-    __device__ __forceinline__ void merge_sorted(const S *ls, const uint32_t *lr) {
-        for (int i = 0; i < k; ++i) {
-            const S cs = ls[i];
-            const uint32_t cr = lr[i];
-            if (!admits(cs, cr)) break;
-            insert(cs, cr);
+    // Offer one candidate per flagged lane (flag already includes admits()).  Few candidates: wave-uniform
+    // insertion loop.  Many (the first rounds of a merge, BM25's dense slices): sort them and merge networks,
+    // whose cost does not depend on the count.
+    __device__ __forceinline__ void offer_lanes(bool flag, S cs, uint32_t cr) {
+        unsigned long long m = __ballot(flag);
+        if (m == 0) return;
+        if (__builtin_popcountll(m) <= 5) {
+            while (m) {
+                const int l = __builtin_ctzll(m);
+                m &= m - 1;
+                const S us = read_lane(cs, l);
+                const uint32_t ur = read_lane(cr, l);
+                if (admits(us, ur)) insert(us, ur);
+            }
+            return;
         }
+        S ss = flag ? cs : neg_inf<S>();
+        uint32_t sr = flag ? cr : kNoRow;
+        bitonic_sort64(ss, sr);
+        const int rev = kWave - 1 - lane_id();
+        merge_reversed(__shfl(ss, rev), __shfl(sr, rev));
+    }
+
+    // Merge a sorted 64-entry list that lives in LDS (lane i reads entry 63-i: the reversal is free).
+    __device__ __forceinline__ void merge_sorted(const S *ls, const uint32_t *lr) {
+        const int rev = kWave - 1 - lane_id();
+        merge_reversed(ls[rev], lr[rev]);
     }
 };
 

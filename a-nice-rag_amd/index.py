@@ -61,9 +61,10 @@ class Index:
             raise nat.AnragError(-3, "index is closed")
         return self._h
 
-    def set_streams(self, primary: int = 0, secondary: int = 0) -> None:
-        """Run on caller-owned HIP streams (e.g. torch.cuda.current_stream().cuda_stream)."""
-        nat.check(self._lib.anrag_index_set_streams(self.handle, primary or None, secondary or None))
+    def set_streams(self, primary: int = 0, secondary: int = 0, fusion: int = 0) -> None:
+        """Run on caller-owned HIP streams (e.g. torch.cuda.current_stream().cuda_stream); 0 = the index's own.
+        Roles: include/anrag.h, anrag_index_set_streams."""
+        nat.check(self._lib.anrag_index_set_streams(self.handle, primary or None, secondary or None, fusion or None))
 
     def sync(self) -> None:
         nat.check(self._lib.anrag_index_sync(self.handle))
@@ -196,8 +197,12 @@ class Index:
         return out_id[:m], out_score[:m]
 
     # ------------------------------------------------------------------ measurement
-    def profile(self, on: bool) -> None:
-        nat.check(self._lib.anrag_profile_enable(self.handle, 1 if on else 0))
+    def profile(self, on, kernels=None) -> None:
+        """Bracket launches with HIP events: on=True times every kernel id, `kernels=[ids]` only those."""
+        mask = 0
+        if on:
+            mask = 0xFFFFFFFF if kernels is None else sum(1 << int(k) for k in kernels)
+        nat.check(self._lib.anrag_profile_enable(self.handle, mask))
 
     def profile_reset(self) -> None:
         nat.check(self._lib.anrag_profile_reset(self.handle))

@@ -6,7 +6,8 @@ The reference has no distributed code at all; this is the 
 
 Per query, on every rank:
     1. local legs          dense scan + BM25 on the rank's rows -> 2k candidate records
-                           (`anrag_hybrid_candidates_device`, compute stream + the index's 2nd stream)
+                           (`anrag_hybrid_candidates_device`: scan on the compute stream, BM25 on the
+                           index's second stream, list merges + copy-out on the communication stream)
     2. exchange            ONE all-gather of 2k x 16 B per rank (k=25: 800 B) -- latency-bound,
                            nowhere near the 7 x 153 GB/s xGMI links, so it runs on a separate
                            communication stream and overlaps the next query's scan
@@ -48,9 +49,11 @@ class HipShardEngine:
         self.device = device
         self.compute_stream = torch.cuda.current_stream(device)
         self.comm_stream = torch.cuda.Stream(device)
-        index.set_streams(self.compute_stream.cuda_stream, 0)
+        # scans on torch's current stream, BM25 on the index's own second stream, and everything that
+        # produces or consumes candidate records on the communication stream, in order with the collective
+        index.set_streams(self.compute_stream.cuda_stream, 0, self.comm_stream.cuda_stream)
         self.aux = Index(index.device)
-        self.aux.set_streams(self.comm_stream.cuda_stream, 0)
+        self.aux.set_streams(0, 0, self.comm_stream.cuda_stream)
         self._lib = index._lib
         from . import _native as nat
 
@@ -96,9 +99,6 @@ class ShardedSearcher:
         self.merged = [mk(2 * self.k) for _ in range(depth)]
         self.out = [mk(self.top_n) for _ in range(depth)]
         self.count = [torch.zeros(1, dtype=torch.int32, device=self.device) for _ in range(depth)]
-        if self.cuda:
-            self.legs_done = [torch.cuda.Event() for _ in range(depth)]
-            self.slot_free = [torch.cuda.Event() for _ in range(depth)]
         self._next = 0
         self._pending: List[int] = []
 
@@ -106,17 +106,10 @@ class ShardedSearcher:
         slot = self._next % self.depth
         self._next += 1
         eng, k = self.engine, self.k
-        if self.cuda:
-            compute, comm = eng.compute_stream, eng.comm_stream
-            if self._next > self.depth:
-                compute.wait_event(self.slot_free[slot])  # the slot's previous exchange has read send[slot]
+        # the engine writes send[slot] in communication-stream order, so the slot's previous all-gather
+        # (same stream) has finished with it and the one below sees the new records: no events needed
         eng.legs(d_query, d_terms, n_terms, k, self.send[slot])
-        if self.cuda:
-            self.legs_done[slot].record(compute)
-            comm.wait_event(self.legs_done[slot])
-            ctx = torch.cuda.stream(comm)
-        else:
-            ctx = _NullCtx()
+        ctx = torch.cuda.stream(eng.comm_stream) if self.cuda else _NullCtx()
         with ctx:
             if self.world > 1:
                 dist.all_gather_into_tensor(self.recv[slot].view(-1), self.send[slot].view(-1), group=self.group)
@@ -126,16 +119,14 @@ class ShardedSearcher:
             eng.merge(self.recv[slot], self.world, k, 2 * k, k, self.merged[slot][k:])
             eng.fuse(self.merged[slot][:k], self.merged[slot][k:], k, self.w_dense, self.w_bm25, self.wrrf_k,
                      self.top_n, self.out[slot], self.count[slot])
-            if self.cuda:
-                self.slot_free[slot].record(comm)
         self._pending.append(slot)
         return slot
 
     def drain(self) -> None:
         """Wait for everything submitted so far."""
         if self.cuda:
+            self.engine.index.sync()
             self.engine.comm_stream.synchronize()
-            self.engine.compute_stream.synchronize()
 
     def result(self, slot: int) -> Tuple[np.ndarray, np.ndarray]:
         """(doc ids, fused fp64 scores) of the query last submitted into `slot` (call drain() first)."""

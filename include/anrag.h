@@ -84,12 +84,17 @@ int anrag_device_count(int *out_count);
  * (database_manager.py:17-18, :65-66, :92-93): the index owns the HBM copies. */
 int anrag_index_create(int device, anrag_index **out);
 int anrag_index_destroy(anrag_index *idx);
-/* Run the index's kernels on caller-owned HIP streams (hipStream_t as void*),
- * e.g. torch.cuda.current_stream().cuda_stream so that RCCL collectives issued
- * through torch.distributed order after them.  NULL = the index's own streams.
- * `secondary` carries the BM25 leg of a hybrid search concurrently with the
- * dense scan on `primary`. */
-int anrag_index_set_streams(anrag_index *idx, void *primary, void *secondary);
+/* Run the index's kernels on caller-owned HIP streams (hipStream_t as void*).
+ * NULL = the index's own streams.  Roles:
+ *   primary    dense scans (and every non-hybrid entry point)
+ *   secondary  the BM25 leg of a hybrid query
+ *   fusion     dense list merge, WRRF, anrag_merge_candidates_device,
+ *              anrag_wrrf_device; the RESULTS of the *_device hybrid entry points
+ *              are complete in fusion-stream order.  Pass the stream a
+ *              torch.distributed (RCCL) collective will be issued on, e.g. a
+ *              torch.cuda.Stream's .cuda_stream, and the collective orders
+ *              after the per-shard candidates with no host sync. */
+int anrag_index_set_streams(anrag_index *idx, void *primary, void *secondary, void *fusion);
 /* Block until everything enqueued on the index's streams has finished. */
 int anrag_index_sync(anrag_index *idx);
 
@@ -187,9 +192,11 @@ int anrag_hybrid_search(anrag_index *idx, const float *query, const int32_t *ter
                         int32_t *out_count);
 
 /* Same, operands in HBM, nothing syncs the host: d_out receives min(top_n,
- * distinct ids) records in fused order, *d_count that number.  Back-to-back
- * queries pipeline: BM25 of query i+1 (secondary stream) runs under the dense
- * scan of query i+1 once the fusion of query i has released its input slots. */
+ * distinct ids) records in fused order, *d_count that number, complete in
+ * fusion-stream order (anrag_index_sync waits for all three streams).
+ * Back-to-back queries pipeline: the scans stay adjacent on the primary stream;
+ * BM25, the list merges and the fusion of query i run under the scan of
+ * query i+1 (double-buffered internally). */
 int anrag_hybrid_search_device(anrag_index *idx, const float *d_query, const int32_t *d_term_ids,
                                int32_t n_terms, int32_t similarity_k, double w_dense,
                                double w_bm25, double wrrf_k, int32_t top_n,
@@ -202,19 +209,21 @@ int anrag_hybrid_search_device(anrag_index *idx, const float *d_query, const int
  * k records each into the global top-k (score desc, doc asc -- row order is
  * shard-local, doc ids are global and ascend with rows under row sharding).
  * List l starts at d_lists + l * list_stride records (list_stride >= k).
- * All device pointers; enqueued on the primary stream. */
+ * All device pointers; enqueued on the fusion stream. */
 int anrag_merge_candidates_device(anrag_index *idx, const anrag_candidate *d_lists,
                                   int32_t n_lists, int32_t k, int64_t list_stride,
                                   anrag_candidate *d_out);
 /* Both legs of a hybrid query on this shard, no fusion: d_out[0..k) = dense
  * candidates, d_out[k..2k) = BM25 candidates -- one rank's all-gather payload.
- * Dense runs on the primary stream, BM25 on the secondary; the primary stream
- * waits for both before anything queued after this call. */
+ * Dense runs on the primary stream, BM25 on the secondary; d_out is written
+ * on the fusion stream, i.e. it is ready for whatever is enqueued on that
+ * stream next (the all-gather). */
 int anrag_hybrid_candidates_device(anrag_index *idx, const float *d_query,
                                    const int32_t *d_term_ids, int32_t n_terms, int32_t k,
                                    const uint32_t *d_allow_dense_bits,
                                    const uint32_t *d_allow_bm25_bits, anrag_candidate *d_out);
-/* WRRF over two device candidate lists (dense, bm25) -> top_n on the device. */
+/* WRRF over two device candidate lists (dense, bm25) -> top_n on the device
+ * (fusion stream). */
 int anrag_wrrf_device(anrag_index *idx, const anrag_candidate *d_dense, int32_t n_dense,
                       const anrag_candidate *d_bm25, int32_t n_bm25, double w_dense,
                       double w_bm25, double k, int32_t top_n, anrag_candidate *d_out,
@@ -228,11 +237,11 @@ int anrag_copy_to_device(anrag_index *idx, void *d_dst, const void *h_src, int64
 int anrag_copy_to_host(anrag_index *idx, void *h_dst, const void *d_src, int64_t bytes);
 
 /* ------------------------------------------------------------------ measurement
- * With profiling on, every launch of the kernels above is bracketed by HIP events
- * on the stream it runs on; anrag_profile_read drains them (syncs the streams)
- * and returns the summed device time and launch count of one kernel id since
- * the last reset. */
-int anrag_profile_enable(anrag_index *idx, int on);
+ * kernel_mask bit i set: every launch of kernel id i is bracketed by HIP events
+ * on the stream it runs on (0 = profiling off).  anrag_profile_read drains them
+ * (waits for the launches) and returns the summed device time and launch count
+ * of one kernel id since the last reset. */
+int anrag_profile_enable(anrag_index *idx, uint32_t kernel_mask);
 int anrag_profile_reset(anrag_index *idx);
 int anrag_profile_read(anrag_index *idx, int kernel_id, double *out_total_ms, int64_t *out_launches);
 /* Shape facts a caller needs for roofline arithmetic. */
