@@ -1,0 +1,189 @@
+"""`RetrievalEvaluationSystem`: the reference's src/query_rag_retrieval.py:20-411 over the GPU
+search engine.  Same constructor behaviour (load every configured DB once, any failure empties the
+source, :105-108), same `retrieve_documents` keyword arguments, defaults, gating, fusion and return
+types -- so a `retrieval_eval.py`-shaped harness is drop-in.
+
+The reference's four cloned per-model blocks (:197-301) are one loop over `Config.DENSE_MODELS`
+(same order), which also admits the local encoder's model key.  When exactly one dense model and
+BM25 are active and k <= 64, the whole query is ONE `anrag_hybrid_search` call; results are
+identical to the method-by-method route (tests/test_gpu_retrieval.py holds both to the reference's
+golden vectors).
+"""
+from __future__ import annotations
+
+import logging
+import time
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+
+from .config import Config, InfoSource
+from .database_manager import DatabaseManager
+from .search_engine import SearchEngine
+
+logger = logging.getLogger(__name__)
+
+
+class RetrievalEvaluationSystem:
+    def __init__(self, config: Optional[Config] = None, voyage_client=None, encoder=None, fused: bool = True):
+        self.config = config or Config()
+        self.db_manager = DatabaseManager()
+        self.voyage_client = voyage_client  # reranking only (remote); None disables it, as :30-34
+        self.search_engine = SearchEngine(voyage_client, None, encoder=encoder)
+        self.fused = fused
+        self._load_databases()
+
+    def _load_databases(self):
+        """query_rag_retrieval.py:38-111."""
+        start = time.time()
+        self.embeddings_data = {}
+        self.bm25_data = {}
+        for source in InfoSource:
+            sc = self.config.SOURCE_CONFIGS[source]
+            try:
+                embeddings_dict = {}
+                for key, attr, loader_name in self.config.DENSE_MODELS:
+                    path = getattr(sc, attr, None)
+                    if path:
+                        embeddings_dict[key] = self.db_manager.load_embeddings_from_sql(path, loader_name)
+                self.embeddings_data[source] = embeddings_dict
+                self.bm25_data[source] = self.db_manager.load_bm25_from_pickle(sc.bm25_path)
+            except Exception as e:
+                from ._native import AnragError
+
+                if isinstance(e, AnragError) and e.code in (-100, -5):
+                    raise  # no library / no GPU is not a data problem
+                logger.error(f"Failed to load {source.value}: {e}")
+                self.embeddings_data[source] = {}
+                self.bm25_data[source] = None
+        logger.info(f"Database loading completed in {time.time() - start:.2f} seconds")
+
+    def _validate_inputs(self, query_embeddings, similarity_k, common_sections_n, info_source):
+        """query_rag_retrieval.py:113-139."""
+        if not query_embeddings:
+            raise ValueError("Query embeddings dictionary cannot be empty")
+        for model_name, embedding in query_embeddings.items():
+            if not isinstance(embedding, np.ndarray):
+                raise ValueError(f"Embedding for {model_name} must be a numpy array")
+            if embedding.size == 0:
+                raise ValueError(f"Embedding for {model_name} cannot be empty")
+        if similarity_k <= 0 or common_sections_n <= 0:
+            raise ValueError("similarity_k and common_sections_n must be positive integers")
+        try:
+            InfoSource(info_source.lower())
+        except ValueError:
+            raise ValueError(f"Invalid info_source '{info_source}'. Must be one of: {[s.value for s in InfoSource]}")
+
+    def get_sources(self, results: List[Tuple], info_source: str) -> List[str]:
+        """query_rag_retrieval.py:141-147."""
+        return [doc.get("id", "Unknown section") for doc, _ in results]
+
+    def retrieve_documents(
+        self,
+        query_embeddings: Dict[str, np.ndarray],
+        query_text: Optional[str] = None,
+        query_tokens: Optional[List[str]] = None,
+        similarity_k: int = 25,
+        common_sections_n: int = 15,
+        info_source: str = "NICE",
+        model_weights: Optional[Dict[str, float]] = None,
+        filename_type_filter: Optional[str] = None,
+        use_hybrid_search: bool = False,
+        wrrf_k: int = 60,
+        use_reranker: bool = True,
+        reranker_model: str = "rerank-2-lite",
+        reranker_top_k: Optional[int] = 5,
+        return_docs: bool = False,
+    ):
+        """query_rag_retrieval.py:149-411."""
+        self._validate_inputs(query_embeddings, similarity_k, common_sections_n, info_source)
+        if model_weights is None:
+            model_weights = self.config.DEFAULT_MODEL_WEIGHTS.copy()
+        source_enum = InfoSource(info_source.lower())
+        try:
+            embeddings_dict = self.embeddings_data.get(source_enum, {})
+            bm25_tuple = self.bm25_data.get(source_enum)
+            if not embeddings_dict:
+                return []
+            bm25, bm25_sections, bm25_section_ids = bm25_tuple if bm25_tuple else (None, [], [])
+
+            active = [(key, embeddings_dict[key]) for key, _, _ in self.config.DENSE_MODELS
+                      if embeddings_dict.get(key) is not None and not embeddings_dict[key].empty
+                      and model_weights.get(key, 0) > 0 and key in query_embeddings]
+            want_bm25 = use_hybrid_search and bm25 is not None and model_weights.get("BM25", 0) > 0
+            will_rerank = use_reranker and bool(query_text)
+
+            # ---- fused single-call route: one dense model + BM25 tokens, ids out, no rerank
+            if (self.fused and not return_docs and not will_rerank and len(active) == 1 and want_bm25
+                    and query_tokens and similarity_k <= 64):
+                key, df = active[0]
+                ids = self.search_engine.hybrid_search_ids(
+                    query_embeddings[key], df, model_weights.get(key, 1.0), query_tokens, bm25, bm25_sections,
+                    bm25_section_ids, model_weights.get("BM25", 1.0), similarity_k, common_sections_n, wrrf_k,
+                    filename_type_filter)
+                if ids is not None:
+                    return ids
+
+            ranked_lists = []
+            all_results: Dict[str, dict] = {}
+            for key, df in active:
+                results = self.search_engine.similarity_search_with_embedding(
+                    query_embeddings[key], df, key, similarity_k, filename_type_filter)
+                if not results.empty:
+                    ranked_lists.append((results["id"].tolist(), key))
+                    for rec in results.to_dict("records"):
+                        all_results.setdefault(rec["id"], rec)
+
+            if want_bm25:
+                bm25_ranked = None
+                if query_tokens:
+                    bm25_ranked = self.search_engine.bm25_search_preprocessed(
+                        query_tokens, bm25, bm25_sections, bm25_section_ids, similarity_k, filename_type_filter)
+                elif query_text:
+                    bm25_ranked = self.search_engine.bm25_search(
+                        query_text, bm25, bm25_sections, bm25_section_ids, similarity_k, filename_type_filter)
+                else:
+                    logger.warning("BM25 search requested but no query_text or query_tokens provided - skipping BM25")
+                if bm25_ranked:
+                    ranked_lists.append((bm25_ranked, "BM25"))
+                    missing = [sid for sid in bm25_ranked if sid not in all_results]
+                    if missing:
+                        section_of = self._section_dict(source_enum, bm25_sections)
+                        for sid in missing:
+                            section = section_of.get(sid)
+                            if section:
+                                all_results[sid] = {"id": sid, "document": section.page_content,
+                                                    "source": section.metadata.get("source", "Unknown"),
+                                                    "similarity": 0.0}
+
+            if len(ranked_lists) > 1:
+                fused = self.search_engine.weighted_reciprocal_rank_fusion(ranked_lists, model_weights, wrrf_k)
+                most_common = [sid for sid, _ in fused[:common_sections_n]]
+            elif len(ranked_lists) == 1:
+                most_common = ranked_lists[0][0][:common_sections_n]
+            else:
+                most_common = []
+            common_docs = [all_results[sid] for sid in most_common if sid in all_results][:common_sections_n]
+
+            if use_reranker and common_docs and len(common_docs) > 1 and query_text:
+                common_docs = self.search_engine.rerank_documents(query_text, common_docs, reranker_model,
+                                                                  reranker_top_k)
+            if return_docs:
+                return common_docs
+            final = [(doc, doc.get("rerank_score", doc.get("similarity", 0.0))) for doc in common_docs]
+            return self.get_sources(final, info_source)
+        except Exception as e:
+            from ._native import AnragError
+
+            if isinstance(e, AnragError) and e.code in (-100, -5):
+                raise
+            logger.error(f"Error in retrieval processing: {e}")
+            return []
+
+    def _section_dict(self, source_enum, bm25_sections):
+        # the reference rebuilds this dict over all sections on EVERY query (:192); once is enough
+        cache = self.__dict__.setdefault("_section_dicts", {})
+        d = cache.get(source_enum)
+        if d is None:
+            d = cache[source_enum] = {s.metadata["id"]: s for s in bm25_sections}
+        return d

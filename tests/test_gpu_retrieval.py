@@ -1,0 +1,159 @@
+"""GPU: the reference-shaped host layer (DatabaseManager / SearchEngine / RetrievalEvaluationSystem) end to end
+over real SQLite `chunks` DBs and a BM25 pickle, against the ids the REFERENCE's own retrieve_documents returned
+(tests/golden/ref_end_to_end.json) -- through both routes: method-by-method and the fused single ABI call."""
+import os
+import pickle
+import sqlite3
+
+import numpy as np
+import pandas as pd
+import pytest
+
+from helpers import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _write_db(path, chunks, e):
+    conn = sqlite3.connect(path)
+    conn.execute("CREATE TABLE chunks (id TEXT PRIMARY KEY, content TEXT NOT NULL, source TEXT NOT NULL,"
+                 " embedding BLOB NOT NULL, created_at TIMESTAMP DEFAULT CURRENT_TIMESTAMP, url TEXT)")
+    for c, v in zip(chunks, e):
+        conn.execute("INSERT INTO chunks (id, content, source, embedding, url) VALUES (?,?,?,?,?)",
+                     (c["id"], " ".join(c["tokens"]) or "-", c["source"], np.asarray(v, np.float32).tobytes(), None))
+    conn.commit()
+    conn.close()
+
+
+@pytest.fixture(scope="module")
+def world(tmp_path_factory):
+    from oracle.make_golden import Document, synth_dense
+    from oracle.ref_bm25 import BM25Okapi
+    from anrag.config import Config, InfoSource
+
+    g = load_golden("ref_end_to_end.json")
+    co = g["corpus"]
+    chunks = co["chunks"]
+    tmp = tmp_path_factory.mktemp("anrag_e2e")
+    e1 = synth_dense(co["n"], co["d"], co["e1_seed"])
+    e2 = synth_dense(co["n"], co["d"], co["e2_seed"])
+    db1, db2, pkl = str(tmp / "m1.db"), str(tmp / "m2.db"), str(tmp / "bm25.pkl")
+    _write_db(db1, chunks, e1)
+    _write_db(db2, chunks, e2)
+    kept = [c for c in chunks if c["tokens"]]
+    # the pickle holds a rank_bm25-SHAPED object (the oracle's restatement: rank_bm25 itself is not installed)
+    bm25 = BM25Okapi([c["tokens"] for c in kept], k1=1.7, b=0.83, epsilon=0.05)
+    sections = [Document(" ".join(c["tokens"]), {"id": c["id"], "source": c["source"]}) for c in kept]
+    with open(pkl, "wb") as f:
+        pickle.dump({"bm25": bm25, "sections": sections, "section_ids": [c["id"] for c in kept], "config": {}}, f)
+    cfg = Config()
+    sc = cfg.SOURCE_CONFIGS[InfoSource.NICE]
+    saved = dict(vars(sc))
+    sc.db_path = sc.voyage_db_path = db1
+    sc.openai_db_path = db2
+    sc.voyage_3_5_db_path = sc.qwen_db_path = sc.local_db_path = None
+    sc.bm25_path = pkl
+    yield g, cfg, e1, e2, kept
+    for k, v in saved.items():
+        setattr(sc, k, v)
+
+
+@pytest.mark.parametrize("fused", [False, True])
+def test_retrieve_documents_matches_reference(world, fused):
+    from oracle.make_golden import synth_query
+    from anrag.query_rag_retrieval import RetrievalEvaluationSystem
+
+    g, cfg, e1, e2, kept = world
+    system = RetrievalEvaluationSystem(cfg, fused=fused)
+    for c in g["cases"]:
+        q = {"voyage-3-large": synth_query(e1, c["q1_seed"], c["target"]),
+             "text-embedding-3-large": synth_query(e2, c["q2_seed"], c["target"])}
+        out = system.retrieve_documents(query_embeddings=q, query_tokens=c["tokens"], use_reranker=False, **c["cfg"])
+        assert out == c["ids"], (fused, c["cfg"], c["tokens"])
+
+
+def test_database_manager_contract(world):
+    from anrag.database_manager import ATTR, Bm25Proxy, DatabaseManager
+    from anrag.config import InfoSource
+
+    g, cfg, e1, e2, kept = world
+    sc = cfg.SOURCE_CONFIGS[InfoSource.NICE]
+    dm = DatabaseManager()
+    df = dm.load_embeddings_from_sql(sc.db_path, "voyage-3-large")
+    assert list(df.columns) == ["id", "document", "source", "embedding", "url"]
+    assert len(df) == g["corpus"]["n"] and df["embedding"].iloc[0].dtype == np.float32
+    assert dm.load_embeddings_from_sql(sc.db_path, "voyage-3-large") is df  # cached (database_manager.py:27-29)
+    assert ATTR in df.attrs
+    bm25, sections, section_ids = dm.load_bm25_from_pickle(sc.bm25_path)
+    assert isinstance(bm25, Bm25Proxy) and len(sections) == len(section_ids) == len(kept)
+    # the proxy answers like the pickled object did
+    from oracle.ref_bm25 import BM25Okapi
+
+    ref = BM25Okapi([c["tokens"] for c in kept], k1=1.7, b=0.83, epsilon=0.05)
+    for toks in (["asthma", "dose"], ["insulin", "insulin", "nothere"], []):
+        assert np.array_equal(bm25.get_scores(toks), ref.get_scores(toks))
+    with pytest.raises(FileNotFoundError):
+        dm.load_embeddings_from_sql("/nonexistent.db")
+    with pytest.raises(FileNotFoundError):
+        dm.load_bm25_from_pickle("/nonexistent.pkl")
+
+
+def test_search_engine_surface(world):
+    from oracle import ref_search
+    from oracle.make_golden import synth_query
+    from anrag.database_manager import DatabaseManager
+    from anrag.config import InfoSource
+    from anrag.search_engine import SearchEngine
+
+    g, cfg, e1, e2, kept = world
+    sc = cfg.SOURCE_CONFIGS[InfoSource.NICE]
+    dm = DatabaseManager()
+    df = dm.load_embeddings_from_sql(sc.db_path)
+    bm25, sections, section_ids = dm.load_bm25_from_pickle(sc.bm25_path)
+    se = SearchEngine(None, None)
+    q = synth_query(e1, 1, 17)
+    r = se.similarity_search_with_embedding(q, df, "m", 10, "CG,NG")
+    rows, sims = ref_search.similarity_search_with_embedding(q, e1, df["source"].tolist(), 10, "CG,NG", canonical=True)
+    assert r.index.tolist() == rows.tolist() and list(r.columns)[-1] == "similarity"
+    assert np.max(np.abs(r["similarity"].to_numpy() - sims)) <= 1e-4 and r["similarity"].dtype == np.float32
+    assert se.similarity_search_with_embedding(q.astype(np.float64), df, "m", 3)["similarity"].dtype == np.float64
+    assert se.similarity_search_with_embedding(q, df, "m", 10, "ZZ").empty          # filter leaves nothing (:71-75)
+    assert se.similarity_search_with_embedding(np.stack([q, q]), df, "m", 3).empty  # batched query: reference errors -> empty
+    assert se.similarity_search("text", df, "voyage-3-large", 5).empty               # no Voyage client: logged, empty (:144-146)
+    assert se.similarity_search("text", df, "m", 5, None, q).index.tolist() == r.index.tolist()[:0] + \
+        se.similarity_search_with_embedding(q, df, "m", 5).index.tolist()
+    # a frame that never saw DatabaseManager still searches on the GPU
+    plain = pd.DataFrame({"id": df["id"], "source": df["source"], "embedding": list(e1)})
+    assert se.similarity_search_with_embedding(q, plain, "m", 5).index.tolist() == \
+        se.similarity_search_with_embedding(q, df, "m", 5).index.tolist()
+    assert se.bm25_search_preprocessed([], bm25, sections, section_ids) == []
+    ids = se.bm25_search_preprocessed(["asthma", "dose"], bm25, sections, section_ids, 5, "NG")
+    assert len(ids) == 5 and all(i.upper().startswith("NG") for i in ids)
+    assert se.bm25_search("What dose of asthma inhalers?", bm25, sections, section_ids, 5) == \
+        se.bm25_search_preprocessed(["dose", "asthma", "inhaler"], bm25, sections, section_ids, 5)
+    fused = se.weighted_reciprocal_rank_fusion([(["a", "b", "c"], "m1"), (["c", "a", "d"], "BM25")],
+                                               {"m1": 5.0, "BM25": 1.0}, 40)
+    assert fused == ref_search.weighted_reciprocal_rank_fusion([(["a", "b", "c"], "m1"), (["c", "a", "d"], "BM25")],
+                                                               {"m1": 5.0, "BM25": 1.0}, 40)
+
+
+def test_evaluator_and_metrics(world):
+    from anrag.query_rag_retrieval import RetrievalEvaluationSystem
+    from anrag.retrieval_eval import RetrievalEvaluator, calculate_metrics
+    from oracle.make_golden import synth_query
+
+    g, cfg, e1, e2, kept = world
+    ev = RetrievalEvaluator(retrieval_system=RetrievalEvaluationSystem(cfg))
+    params = dict(similarity_k=25, common_sections_n=15, model_weights={"voyage-3-large": 5.0, "BM25": 1.0},
+                  use_hybrid_search=True, wrrf_k=40, filename_type_filter=None)
+    results = []
+    for i in range(20):
+        target = (i * 7) % len(g["corpus"]["chunks"])
+        q = synth_query(e1, 2000 + i, target)
+        results.append(ev.evaluate_query("q", g["corpus"]["chunks"][target]["id"], {"voyage-3-large": q}, params,
+                                         g["corpus"]["chunks"][target]["tokens"][:4]))
+    m = calculate_metrics(results)
+    assert m["recall@1"] >= 0.9 and m["total"] == 20
+    for c in load_golden("ref_metrics.json"):
+        got = {k: (None if v is None else float(v)) for k, v in calculate_metrics(c["results"]).items()}
+        assert got == c["metrics"]
