@@ -89,7 +89,8 @@ class ShardedSearcher:
         self.k, self.top_n = int(k), int(top_n)
         self.w_dense, self.w_bm25, self.wrrf_k = float(w_dense), float(w_bm25), float(wrrf_k)
         self.group = group
-        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.distributed = dist.is_initialized()
+        self.world = dist.get_world_size(group) if self.distributed else 1
         self.device = device if device is not None else torch.device("cpu")
         self.cuda = self.device.type == "cuda"
         self.depth = depth
@@ -111,7 +112,7 @@ class ShardedSearcher:
         eng.legs(d_query, d_terms, n_terms, k, self.send[slot])
         ctx = torch.cuda.stream(eng.comm_stream) if self.cuda else _NullCtx()
         with ctx:
-            if self.world > 1:
+            if self.distributed:
                 dist.all_gather_into_tensor(self.recv[slot].view(-1), self.send[slot].view(-1), group=self.group)
             else:
                 self.recv[slot].view(-1).copy_(self.send[slot].view(-1))

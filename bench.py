@@ -58,8 +58,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    # ANRAG_FORCE_SHARDED=1: take the sharded (all-gather) route even at world size 1 -- a rehearsal of the
+    # N > 1 code path on a one-GPU box
+    sharded = world > 1 or os.environ.get("ANRAG_FORCE_SHARDED") == "1"
+    if sharded:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world,
                                 device_id=torch.device("cuda", local_rank))
     if world != args.gpus and rank == 0:
@@ -119,7 +123,7 @@ def main():
 
     # ------------------------------------------------------------------ the step
     lib = nat.load_library()
-    if world == 1:
+    if not sharded:
         out = torch.zeros((args.queries, TOPN, 2), dtype=torch.int64, device=device)
         cnt = torch.zeros(args.queries, dtype=torch.int32, device=device)
 
@@ -218,12 +222,12 @@ def main():
             },
             "index_build_s": build_s,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if not sharded and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args, E, Q, post, idf if hybrid else None,
                                                 avgdl if hybrid else None, term_lists, out, cnt, hybrid, K, TOPN,
                                                 (W_DENSE, W_BM25, WRRF_K))
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if sharded:
         dist.barrier()
         dist.destroy_process_group()
 

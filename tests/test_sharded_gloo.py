@@ -1,0 +1,150 @@
+"""CPU, world_size 2, gloo: the sharded path's host logic (row partition, one all-gather of per-shard
+candidate records, replicated merge, fusion on global ranks).  The HIP shard engine cannot run here, so
+the ORACLE stands in for it (test infrastructure: the product `HipShardEngine` has no such fallback);
+what is under test is `anrag.sharded.ShardedSearcher` + torch.distributed plumbing."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import ref_search
+from oracle.make_golden import synth_chunks, synth_dense, synth_query
+from oracle.ref_bm25 import CsrBM25, csr_get_scores
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+class OracleShardEngine:
+    """Duck-types anrag.sharded.HipShardEngine on CPU tensors."""
+
+    def __init__(self, e_local, lo, glob: CsrBM25, corpus_local):
+        self.e, self.lo = e_local, lo
+        self.glob = glob
+        # shard-local postings over the GLOBAL vocabulary, global idf / avgdl
+        n_terms = len(glob.vocab)
+        plists = [[] for _ in range(n_terms)]
+        tfs = [[] for _ in range(n_terms)]
+        for d, doc in enumerate(corpus_local):
+            counts = {}
+            for w in doc:
+                counts[glob.term_id[w]] = counts.get(glob.term_id[w], 0) + 1
+            for t, c in counts.items():
+                plists[t].append(d)
+                tfs[t].append(c)
+        df = np.array([len(p) for p in plists], dtype=np.int64)
+        self.indptr = np.zeros(n_terms + 1, dtype=np.int64)
+        np.cumsum(df, out=self.indptr[1:])
+        self.post_doc = np.array([d for p in plists for d in p], dtype=np.int32)
+        self.post_tf = np.array([c for p in tfs for c in p], dtype=np.int32)
+        self.doc_len = np.array([len(d) for d in corpus_local], dtype=np.int32)
+
+    @staticmethod
+    def _write(out, docs, scores, k):
+        rec = np.zeros((k, 2), dtype=np.int64)
+        rec[:, 0] = np.array([-np.inf] * k).view(np.int64)
+        rec[:, 1] = -1
+        rec[: len(docs), 0] = np.asarray(scores, dtype=np.float64).view(np.int64)
+        rec[: len(docs), 1] = docs
+        out.copy_(torch.from_numpy(rec))
+
+    def legs(self, d_query, d_terms, n_terms, k, out):
+        q = d_query.numpy()
+        sims = ref_search.dense_scores(q, self.e)
+        top = ref_search.canonical_topk(sims, k)
+        self._write(out[:k], top + self.lo, sims[top].astype(np.float64), k)
+        terms = d_terms.numpy()[:n_terms].tolist()
+        sc = csr_get_scores(self.indptr, self.post_doc, self.post_tf, self.glob.idf, self.doc_len, self.glob.avgdl,
+                            self.glob.k1, self.glob.b, terms)
+        top = ref_search.canonical_topk(sc, k)
+        self._write(out[k:], top + self.lo, sc[top], k)
+
+    def merge(self, lists, n_lists, k, stride, offset, out):
+        rec = lists.numpy().reshape(-1, 2)
+        cands = []
+        for l in range(n_lists):
+            for r in rec[l * stride + offset: l * stride + offset + k]:
+                if r[1] >= 0:
+                    cands.append((float(np.int64(r[0]).view(np.float64)), int(r[1])))
+        cands.sort(key=lambda c: (-c[0], c[1]))
+        cands = cands[:k]
+        self._write(out, [c[1] for c in cands], [c[0] for c in cands], k)
+
+    def fuse(self, dense, bm25, k, w_dense, w_bm25, wrrf_k, top_n, out, count):
+        dl = [int(d) for d in dense.numpy()[:, 1] if d >= 0]
+        bl = [int(d) for d in bm25.numpy()[:, 1] if d >= 0]
+        fused = ref_search.weighted_reciprocal_rank_fusion([(dl, "d"), (bl, "b")], {"d": w_dense, "b": w_bm25},
+                                                           int(wrrf_k))[:top_n]
+        self._write(out, [i for i, _ in fused], [s for _, s in fused], top_n)
+        count.fill_(len(fused))
+
+
+def _worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from anrag.sharded import ShardedSearcher, shard_bounds
+
+    n, d, k, top_n = 301, 32, 25, 10
+    chunks = [c for c in synth_chunks(n + 20, 5) if c["tokens"]][:n]
+    corpus = [c["tokens"] for c in chunks]
+    e = synth_dense(n, d, 6)
+    glob = CsrBM25(corpus, k1=1.7, b=0.83, epsilon=0.05)
+    lo, hi = shard_bounds(n, world, rank)
+    eng = OracleShardEngine(e[lo:hi], lo, glob, corpus[lo:hi])
+    searcher = ShardedSearcher(eng, k=k, top_n=top_n, w_dense=5.0, w_bm25=1.0, wrrf_k=40, depth=2)
+    rng = np.random.default_rng(11)
+    ok = True
+    for trial in range(6):
+        target = int(rng.integers(n))
+        q = synth_query(e, 100 + trial, target)
+        toks = [str(t) for t in rng.choice(corpus[target], size=4)]
+        terms = np.array(glob.term_ids(toks), dtype=np.int32)
+        slot = searcher.submit(torch.from_numpy(q), torch.from_numpy(terms), len(terms))
+        searcher.drain()
+        ids, scores = searcher.result(slot)
+        # single-index oracle
+        sims = ref_search.dense_scores(q, e)
+        dl = ref_search.canonical_topk(sims, k).tolist()
+        bl = ref_search.canonical_topk(glob.get_scores(toks), k).tolist()
+        want = ref_search.weighted_reciprocal_rank_fusion([(dl, "d"), (bl, "b")], {"d": 5.0, "b": 1.0}, 40)[:top_n]
+        ok = ok and ids.tolist() == [i for i, _ in want] and scores.tolist() == [s for _, s in want]
+    t = torch.tensor([1 if ok else 0])
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    if rank == 0:
+        ret.put(int(t.item()))
+    dist.destroy_process_group()
+
+
+def test_shard_bounds_cover_rows():
+    from anrag.sharded import shard_bounds
+
+    for n in (1, 7, 8, 1_000_000, 1_000_003):
+        for world in (1, 2, 3, 8):
+            spans = [shard_bounds(n, world, r) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_sharded_search_world_size_2_gloo():
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, ret)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0, f"rank exited with {p.exitcode}"
+    assert ret.get(timeout=5) == 1
