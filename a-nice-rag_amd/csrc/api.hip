@@ -216,6 +216,7 @@ int anrag_index_create(int device, anrag_index **out) {
 }
 
 static void free_dense(anrag_index *idx) {
+    free_batched(idx);
     dev_free(idx, idx->d_emb, idx->n_rows * idx->dim);
     dev_free(idx, idx->d_dense_src, idx->n_rows);
     dev_free(idx, idx->d_dense_doc, idx->n_rows);
@@ -240,6 +241,7 @@ int anrag_index_destroy(anrag_index *idx) {
         for (void *p : ptrs)
             if (p) (void)hipFree(p);
         free_wrrf_scratch(idx);
+        free_batched(idx);
         if (idx->h_pinned) (void)hipHostFree(idx->h_pinned);
         for (hipEvent_t e : idx->event_pool) (void)hipEventDestroy(e);
         if (idx->ev_fork) (void)hipEventDestroy(idx->ev_fork);
@@ -354,6 +356,80 @@ int anrag_dense_scores(anrag_index *idx, const float *query, float *out_scores) 
     return ANRAG_OK;
 }
 
+// n_queries >= 16 on a large corpus: K2 passes of up to 256 queries; a query whose survivor list overflowed
+// (flag -1: adversarial threshold sample) is redone by the batch = 1 scan.
+static int dense_search_batched_host(anrag_index *idx, hipStream_t st, const float *queries, int32_t n_queries,
+                                     int32_t k, const uint32_t *d_allow, int64_t *out_doc, float *out_score,
+                                     int32_t *out_count) {
+    int rc;
+    if ((rc = ensure_query_buffer(idx, (int64_t)256 * idx->dim))) return rc;
+    std::vector<anrag_candidate> h((size_t)256 * k);
+    std::vector<int32_t> flag(256);
+    anrag_candidate *d_out = nullptr;
+    int32_t *d_flag = nullptr;
+    ANRAG_HIP(hipMalloc(reinterpret_cast<void **>(&d_out), (size_t)256 * k * sizeof(anrag_candidate)));
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&d_flag), 256 * sizeof(int32_t));
+    if (e != hipSuccess) {
+        (void)hipFree(d_out);
+        set_error("hipMalloc failed: %s", hipGetErrorString(e));
+        return ANRAG_ERR_NOMEM;
+    }
+    rc = ANRAG_OK;
+    for (int32_t q0 = 0; q0 < n_queries && rc == ANRAG_OK; q0 += 256) {
+        const int32_t nq = std::min(256, n_queries - q0);
+        e = hipMemcpyAsync(idx->d_query, queries + (int64_t)q0 * idx->dim, (size_t)nq * idx->dim * sizeof(float),
+                           hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) rc = launch_dense_batched(idx, st, idx->d_query, nq, k, d_allow, d_out, d_flag);
+        if (e == hipSuccess && rc == ANRAG_OK)
+            e = hipMemcpyAsync(h.data(), d_out, (size_t)nq * k * sizeof(anrag_candidate), hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess && rc == ANRAG_OK)
+            e = hipMemcpyAsync(flag.data(), d_flag, (size_t)nq * sizeof(int32_t), hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess && rc == ANRAG_OK) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) {
+            set_error("batched dense search failed: %s", hipGetErrorString(e));
+            rc = ANRAG_ERR_HIP;
+            break;
+        }
+        for (int32_t qi = 0; qi < nq && rc == ANRAG_OK; ++qi) {
+            if (flag[qi] != 0) {  // redo with K1
+                rc = launch_dense_topk(idx, st, idx->d_query + (int64_t)qi * idx->dim, k, d_allow, idx->d_cand_out, nullptr);
+                if (rc == ANRAG_OK) {
+                    e = hipMemcpyAsync(h.data() + (size_t)qi * k, idx->d_cand_out, (size_t)k * sizeof(anrag_candidate),
+                                       hipMemcpyDeviceToHost, st);
+                    if (e == hipSuccess) e = hipStreamSynchronize(st);
+                    if (e != hipSuccess) {
+                        set_error("dense redo failed: %s", hipGetErrorString(e));
+                        rc = ANRAG_ERR_HIP;
+                    }
+                }
+            }
+            int32_t cnt = 0;
+            for (int32_t i = 0; i < k; ++i) {
+                const anrag_candidate &c = h[(size_t)qi * k + i];
+                out_doc[(int64_t)(q0 + qi) * k + i] = c.doc;
+                out_score[(int64_t)(q0 + qi) * k + i] = (float)c.score;
+                if (c.doc >= 0) ++cnt;
+            }
+            out_count[q0 + qi] = cnt;
+        }
+    }
+    (void)hipFree(d_out);
+    (void)hipFree(d_flag);
+    return rc;
+}
+
+int anrag_dense_search_batch_device(anrag_index *idx, const float *d_queries, int32_t n_queries, int32_t k,
+                                    const uint32_t *d_allow_bits, anrag_candidate *d_out, int32_t *d_flag) {
+    ANRAG_ENTER(idx);
+    if (int rc0 = settle_pipeline(idx)) return rc0;
+    ANRAG_REQUIRE(idx->d_emb != nullptr, "dense search before anrag_dense_load");
+    ANRAG_REQUIRE(d_queries && d_out && d_flag, "NULL operand");
+    ANRAG_REQUIRE(n_queries >= 1 && n_queries <= 256, "a batched pass takes 1..256 queries");
+    ANRAG_REQUIRE(k > 0 && k <= ANRAG_FUSED_K_MAX, "1 <= k <= %d", ANRAG_FUSED_K_MAX);
+    ANRAG_REQUIRE(idx->dim % 32 == 0, "the MFMA path needs dim %% 32 == 0 (dim = %d)", idx->dim);
+    return launch_dense_batched(idx, idx->primary, d_queries, n_queries, k, d_allow_bits, d_out, d_flag);
+}
+
 int anrag_dense_search(anrag_index *idx, const float *queries, int32_t n_queries, int32_t k,
                        const uint8_t *allow_source, int32_t n_sources, int64_t *out_doc, float *out_score,
                        int32_t *out_count) {
@@ -370,6 +446,8 @@ int anrag_dense_search(anrag_index *idx, const float *queries, int32_t n_queries
     if (k > ANRAG_FUSED_K_MAX) {
         return dense_search_large_k(idx, st, queries, n_queries, k, d_allow, out_doc, out_score, out_count);
     }
+    if (batched_path_applies(idx, n_queries, k))
+        return dense_search_batched_host(idx, st, queries, n_queries, k, d_allow, out_doc, out_score, out_count);
     anrag_candidate *h_cand = reinterpret_cast<anrag_candidate *>(static_cast<char *>(idx->h_pinned) + 8192);
     const int32_t chunk = (int32_t)std::min<int64_t>(64, idx->cand_cap / k);
     for (int32_t q0 = 0; q0 < n_queries; q0 += chunk) {

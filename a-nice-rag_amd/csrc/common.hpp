@@ -107,6 +107,11 @@ struct anrag_index {
     int64_t sort_tmp_bytes = 0;
     void *d_sort_buf = nullptr;
     int64_t sort_buf_bytes = 0;
+    // K2 (batched queries) workspace
+    float *d_bq = nullptr, *d_btau = nullptr, *d_bsample = nullptr;
+    int32_t *d_bcnt = nullptr, *d_bflag = nullptr;
+    void *d_bcand = nullptr;
+    int64_t bsample_cap = 0;
     // WRRF scratch
     int64_t *d_w_ids = nullptr, *d_w_in = nullptr;
     double *d_w_contrib = nullptr, *d_w_score = nullptr;
@@ -148,6 +153,11 @@ int launch_dense_merge(anrag_index *idx, hipStream_t stream, int n_lists, int32_
 // scan + merge on one stream (set 0)
 int launch_dense_topk(anrag_index *idx, hipStream_t stream, const float *d_query, int32_t k,
                       const uint32_t *d_allow_bits, anrag_candidate *d_out, float *d_scores_out);
+// K2: up to 256 queries per pass on the fp32 matrix cores (dense_batched.hip)
+bool batched_path_applies(const anrag_index *idx, int32_t n_queries, int32_t k);
+int launch_dense_batched(anrag_index *idx, hipStream_t st, const float *d_queries, int32_t nq, int32_t k,
+                         const uint32_t *d_allow_bits, anrag_candidate *d_out, int32_t *d_flag);
+void free_batched(anrag_index *idx);
 // k > ANRAG_FUSED_K_MAX: score array + radix sort (select.hip); host operands, syncs.
 int dense_search_large_k(anrag_index *idx, hipStream_t stream, const float *h_queries, int32_t n_queries, int32_t k,
                          const uint32_t *d_allow_bits, int64_t *out_doc, float *out_score, int32_t *out_count);

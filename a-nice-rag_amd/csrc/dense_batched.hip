@@ -1,0 +1,333 @@
+// K2 -- batched queries: S = E . Q^T on the fp32 matrix cores + exact top-k, for Q up to 256 per pass.
+//
+// No reference counterpart (the reference is batch = 1 only, src/search_engine.py:77-81; the oracle is a
+// loop of the single-query path).  BASELINE.json config "1M x 768 dense, batch=256 queries (MFMA
+// batched-GEMM path)".  Arithmetic: v_mfma_f32_32x32x2_f32 -- f32 in, f32 accumulate, bit-for-bit an
+// fmaf chain (k order permuted), so scores stay within the 1e-4 bar of the fp32 reference; no bf16/fp16
+// rounding of the corpus.  2*Q*N*D = 3.93e11 flop per 256-query pass vs 157.3 TFLOP/s dense f32 peak:
+// MFMA-bound (the 3.07 GB corpus is read once per pass: 1.2 TB/s at peak rate).
+//
+// Exact top-k without materialising the Q x N score matrix (1 GB at 256 x 1M):
+//   1. SAMPLE pass   the same GEMM over every (N/S)-th corpus row -> scores[Q][S]; a wave per query
+//                    takes the k-th best allowed sampled score tau_q.  The k-th best over ALL rows is
+//                    >= the k-th best over a subset, so tau_q is a valid lower bound.
+//   2. FILTER pass   the full GEMM; the epilogue appends (score,row) with score >= tau_q to the
+//                    query's candidate list (one global atomic per survivor; ~N*k/S survivors per query).
+//   3. SELECT        a wave per query ranks its survivors (score desc, row asc) -> k records.
+//   A query whose list overflows its capacity is flagged (count = -1) and redone by K1.
+//
+// Tiling (wave64, 8 waves = 512 threads, 2 waves per SIMD so one wave's LDS/barrier waits hide under the
+// other's MFMAs): workgroup tile = 128 corpus rows x 256 queries, BK = 32; corpus rows are the MFMA A
+// operand (rows of D), queries the B operand (columns of D), so a LANE owns one query column and its
+// threshold.  Wave w: rows (w&1)*64.., queries (w>>1)*64.. -> 2x2 tiles of 32x32 = 64 accumulators.
+// LDS images [row][32 k + 4 pad] fp32 (pad breaks the 128-B row stride for ds_read_b128), double
+// buffered (110 KB); global -> registers -> LDS staging issued one k-step ahead.  Each lane reads FOUR
+// consecutive k per ds_read_b128 and feeds them to four MFMAs: MFMA s of group g sums k = 8g+s (lane
+// half 0) and k = 8g+4+s (lane half 1) -- a permutation of k, identical on the A and B side.
+#include "common.hpp"
+#include "wave_topk.hpp"
+
+namespace anrag {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kBM = 128;         // corpus rows per workgroup tile
+constexpr int kBQ = 256;         // queries per pass
+constexpr int kBK = 32;          // k per staging step
+constexpr int kLdk = kBK + 4;    // padded LDS row (floats)
+constexpr int kBatchThreads = 512;
+constexpr int kBufFloats = (kBM + kBQ) * kLdk;
+constexpr int kBatchLdsBytes = 2 * kBufFloats * 4;
+
+struct Cand32 {
+    float score;
+    uint32_t row;
+};
+
+template <bool SAMPLE, bool FILTER>
+__global__ __launch_bounds__(kBatchThreads, 2) void dense_batched_kernel(
+    const float *__restrict__ emb, const float *__restrict__ queries /* [kBQ][dim], zero padded */,
+    int64_t n_rows /* corpus rows */, int32_t dim, int32_t nq, int64_t n_work /* rows this pass visits */,
+    int64_t stride /* SAMPLE: corpus row = work row * stride */, const float *__restrict__ tau,
+    float *__restrict__ sample_scores /* [kBQ][n_work] */, int32_t *__restrict__ cnt, Cand32 *__restrict__ cand,
+    int32_t cap, const uint16_t *__restrict__ src, const uint32_t *__restrict__ allow_bits) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    __shared__ __attribute__((aligned(16))) uint32_t lds_allow[FILTER ? 2048 : 4];  // 16-B multiple: keeps the dynamic base aligned
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int rw = wave & 1, qw = wave >> 1;
+    if constexpr (FILTER) {
+        for (int i = tid; i < 2048; i += kBatchThreads) lds_allow[i] = allow_bits[i];
+    }
+    const int ksteps = dim / kBK;
+    const int64_t n_tiles = (n_work + kBM - 1) / kBM;
+    const int64_t my_tiles = blockIdx.x < n_tiles ? (n_tiles - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
+    const int64_t total = my_tiles * ksteps;
+
+    // this lane's thresholds: query columns qw*64 + tj*32 + l31
+    float my_tau[2] = {0.f, 0.f};
+    if constexpr (!SAMPLE) {
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj) my_tau[tj] = tau[qw * 64 + tj * 32 + l31];
+    }
+
+    f32x4 stage_e[2], stage_q[4];
+    auto load_stage = [&](int64_t it) {
+        const int64_t tile = blockIdx.x + (it / ksteps) * gridDim.x;
+        const int ks = (int)(it % ksteps);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int f = tid + i * kBatchThreads;
+            int64_t wr = tile * kBM + (f >> 3);
+            if (wr >= n_work) wr = n_work - 1;
+            const int64_t row = SAMPLE ? wr * stride : wr;
+            stage_e[i] = *reinterpret_cast<const f32x4 *>(emb + row * dim + ks * kBK + (f & 7) * 4);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int f = tid + i * kBatchThreads;
+            stage_q[i] = *reinterpret_cast<const f32x4 *>(queries + (int64_t)(f >> 3) * dim + ks * kBK + (f & 7) * 4);
+        }
+    };
+    auto store_stage = [&](int buf) {
+        float *es = lds + buf * kBufFloats;
+        float *qs = es + kBM * kLdk;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int f = tid + i * kBatchThreads;
+            *reinterpret_cast<f32x4 *>(es + (f >> 3) * kLdk + (f & 7) * 4) = stage_e[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int f = tid + i * kBatchThreads;
+            *reinterpret_cast<f32x4 *>(qs + (f >> 3) * kLdk + (f & 7) * 4) = stage_q[i];
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[ti][tj][r] = 0.f;
+
+    if (total > 0) {
+        load_stage(0);
+        store_stage(0);
+    }
+    __syncthreads();
+    for (int64_t it = 0; it < total; ++it) {
+        const int buf = (int)(it & 1);
+        if (it + 1 < total) load_stage(it + 1);
+        const float *es = lds + buf * kBufFloats + (rw * 64 + l31) * kLdk + lh * 4;
+        const float *qs = lds + buf * kBufFloats + kBM * kLdk + (qw * 64 + l31) * kLdk + lh * 4;
+#pragma unroll
+        for (int g = 0; g < kBK / 8; ++g) {
+            f32x4 a[2], b[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                a[t] = *reinterpret_cast<const f32x4 *>(es + t * 32 * kLdk + g * 8);
+                b[t] = *reinterpret_cast<const f32x4 *>(qs + t * 32 * kLdk + g * 8);
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                    for (int tj = 0; tj < 2; ++tj)
+                        acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ti][s], b[tj][s], acc[ti][tj], 0, 0, 0);
+        }
+        if ((int)(it % ksteps) == ksteps - 1) {
+            // ---- epilogue of one 128 x 256 tile: D[row][query], lane = query column, 16 rows per register set
+            const int64_t tile = blockIdx.x + (it / ksteps) * gridDim.x;
+#pragma unroll
+            for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                for (int tj = 0; tj < 2; ++tj) {
+                    const int q = qw * 64 + tj * 32 + l31;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int64_t wr = tile * kBM + rw * 64 + ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        const float s = acc[ti][tj][r];
+                        if constexpr (SAMPLE) {
+                            if (wr < n_work) {
+                                bool ok = true;
+                                if constexpr (FILTER) ok = source_ok(lds_allow, src[wr * stride]);
+                                sample_scores[(int64_t)q * n_work + wr] = ok ? s : neg_inf<float>();
+                            }
+                        } else {
+                            if (s >= my_tau[tj] && wr < n_work && q < nq) {
+                                bool ok = true;
+                                if constexpr (FILTER) ok = source_ok(lds_allow, src[wr]);
+                                if (ok) {
+                                    const int pos = atomicAdd(&cnt[q], 1);
+                                    if (pos < cap) {
+                                        Cand32 c;
+                                        c.score = s;
+                                        c.row = (uint32_t)wr;
+                                        cand[(int64_t)q * cap + pos] = c;
+                                    }
+                                }
+                            }
+                        }
+                        acc[ti][tj][r] = 0.f;
+                    }
+                }
+        }
+        if (it + 1 < total) store_stage(buf ^ 1);
+        __syncthreads();
+    }
+}
+
+// tau[q] = k-th best sampled score of query q (or -inf when fewer than k allowed rows were sampled)
+__global__ __launch_bounds__(64) void batched_threshold_kernel(const float *__restrict__ sample_scores, int64_t n_sample,
+                                                               int32_t k, float *__restrict__ tau,
+                                                               int32_t *__restrict__ cnt) {
+    const int q = blockIdx.x, lane = threadIdx.x;
+    WaveTopK<float> top;
+    top.init(k);
+    const float *s = sample_scores + (int64_t)q * n_sample;
+    for (int64_t i0 = 0; i0 < n_sample; i0 += kWave) {
+        const int64_t i = i0 + lane;
+        const float v = i < n_sample ? s[i] : neg_inf<float>();
+        // rows are only a tie-break here; sample index stands in
+        top.offer_lanes(i < n_sample && v > neg_inf<float>() && top.admits(v, (uint32_t)i), v, (uint32_t)i);
+    }
+    if (lane == 0) {
+        tau[q] = top.thr_r == kNoRow ? neg_inf<float>() : top.thr_s;
+        cnt[q] = 0;
+    }
+}
+
+// rank one query's survivors -> k records; count = -1 flags an overflowed list (caller redoes the query with K1)
+__global__ __launch_bounds__(64) void batched_select_kernel(const Cand32 *__restrict__ cand,
+                                                            const int32_t *__restrict__ cnt, int32_t cap, int32_t k,
+                                                            const int64_t *__restrict__ doc_of_row, int64_t doc_base,
+                                                            anrag_candidate *__restrict__ out,
+                                                            int32_t *__restrict__ out_flag) {
+    const int q = blockIdx.x, lane = threadIdx.x;
+    const int32_t n = cnt[q];
+    WaveTopK<float> top;
+    top.init(k);
+    const Cand32 *c = cand + (int64_t)q * cap;
+    const int32_t m = n < cap ? n : cap;
+    for (int32_t i0 = 0; i0 < m; i0 += kWave) {
+        const int32_t i = i0 + lane;
+        Cand32 v;
+        v.score = neg_inf<float>();
+        v.row = kNoRow;
+        if (i < m) v = c[i];
+        top.offer_lanes(i < m && top.admits(v.score, v.row), v.score, v.row);
+    }
+    if (lane < k) {
+        anrag_candidate r;
+        const bool empty = top.r == kNoRow;
+        r.score = empty ? -__builtin_huge_val() : (double)top.s;
+        r.doc = empty ? -1 : (doc_of_row ? doc_of_row[top.r] : doc_base + (int64_t)top.r);
+        out[(int64_t)q * k + lane] = r;
+    }
+    if (lane == 0) out_flag[q] = n > cap ? -1 : 0;
+}
+
+// ------------------------------------------------------------------ host side
+constexpr int32_t kCandCap = 8192;
+
+bool batched_path_applies(const anrag_index *idx, int32_t n_queries, int32_t k) {
+    return n_queries >= 16 && k <= ANRAG_FUSED_K_MAX && idx->dim % kBK == 0 && idx->n_rows >= 65536;
+}
+
+static int ensure_batched_workspace(anrag_index *idx, int64_t n_sample) {
+    if (!idx->d_bq) {
+        ANRAG_HIP(hipMalloc(reinterpret_cast<void **>(&idx->d_bq), (size_t)kBQ * idx->dim * sizeof(float)));
+        ANRAG_HIP(hipMalloc(reinterpret_cast<void **>(&idx->d_btau), kBQ * sizeof(float)));
+        ANRAG_HIP(hipMalloc(reinterpret_cast<void **>(&idx->d_bcnt), kBQ * sizeof(int32_t)));
+        ANRAG_HIP(hipMalloc(reinterpret_cast<void **>(&idx->d_bflag), kBQ * sizeof(int32_t)));
+        ANRAG_HIP(hipMalloc(reinterpret_cast<void **>(&idx->d_bcand), (size_t)kBQ * kCandCap * sizeof(Cand32)));
+        idx->hbm_bytes += (int64_t)kBQ * idx->dim * 4 + (int64_t)kBQ * kCandCap * 8;
+    }
+    if (idx->bsample_cap < n_sample) {
+        if (idx->d_bsample) (void)hipFree(idx->d_bsample);
+        idx->d_bsample = nullptr;
+        idx->bsample_cap = 0;
+        ANRAG_HIP(hipMalloc(reinterpret_cast<void **>(&idx->d_bsample), (size_t)kBQ * n_sample * sizeof(float)));
+        idx->bsample_cap = n_sample;
+    }
+    return ANRAG_OK;
+}
+
+void free_batched(anrag_index *idx) {
+    void *ptrs[] = {idx->d_bq, idx->d_btau, idx->d_bcnt, idx->d_bflag, idx->d_bcand, idx->d_bsample};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    idx->d_bq = idx->d_btau = idx->d_bsample = nullptr;
+    idx->d_bcnt = idx->d_bflag = nullptr;
+    idx->d_bcand = nullptr;
+    idx->bsample_cap = 0;
+}
+
+// One pass of up to 256 queries (device pointers); d_out: nq x k records, d_flag: nq ints (0 ok, -1 redo).
+int launch_dense_batched(anrag_index *idx, hipStream_t st, const float *d_queries, int32_t nq, int32_t k,
+                         const uint32_t *d_allow_bits, anrag_candidate *d_out, int32_t *d_flag) {
+    ANRAG_REQUIRE(nq >= 1 && nq <= kBQ, "a batched pass takes 1..%d queries", kBQ);
+    const int64_t n = idx->n_rows;
+    const int dim = idx->dim;
+    const uint32_t *allow = idx->d_dense_src ? d_allow_bits : nullptr;
+    // sample size: expected survivors per query = N*k/S = cap/4
+    int64_t n_sample = (4 * n * (int64_t)k + kCandCap - 1) / kCandCap;
+    if (n_sample < 4096) n_sample = 4096;
+    if (n_sample > n) n_sample = n;
+    const int64_t stride = n / n_sample;
+    int rc = ensure_batched_workspace(idx, n_sample);
+    if (rc) return rc;
+    static bool attr_set = false;
+    if (!attr_set) {
+        ANRAG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&dense_batched_kernel<true, false>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, kBatchLdsBytes));
+        ANRAG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&dense_batched_kernel<true, true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, kBatchLdsBytes));
+        ANRAG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&dense_batched_kernel<false, false>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, kBatchLdsBytes));
+        ANRAG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&dense_batched_kernel<false, true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, kBatchLdsBytes));
+        attr_set = true;
+    }
+    // zero-padded query block
+    ANRAG_HIP(hipMemsetAsync(idx->d_bq, 0, (size_t)kBQ * dim * sizeof(float), st));
+    ANRAG_HIP(hipMemcpyAsync(idx->d_bq, d_queries, (size_t)nq * dim * sizeof(float), hipMemcpyDeviceToDevice, st));
+    auto grid_for = [&](int64_t rows) {
+        const int64_t tiles = (rows + kBM - 1) / kBM;
+        return (unsigned)(tiles < idx->n_cus ? tiles : idx->n_cus);
+    };
+    {
+        LaunchTimer t(idx, ANRAG_KERNEL_DENSE_BATCHED, st);
+        if (allow)
+            dense_batched_kernel<true, true><<<grid_for(n_sample), kBatchThreads, kBatchLdsBytes, st>>>(
+                idx->d_emb, idx->d_bq, n, dim, nq, n_sample, stride, nullptr, idx->d_bsample, nullptr, nullptr, 0,
+                idx->d_dense_src, allow);
+        else
+            dense_batched_kernel<true, false><<<grid_for(n_sample), kBatchThreads, kBatchLdsBytes, st>>>(
+                idx->d_emb, idx->d_bq, n, dim, nq, n_sample, stride, nullptr, idx->d_bsample, nullptr, nullptr, 0,
+                nullptr, nullptr);
+        batched_threshold_kernel<<<kBQ, 64, 0, st>>>(idx->d_bsample, n_sample, k, idx->d_btau, idx->d_bcnt);
+        if (allow)
+            dense_batched_kernel<false, true><<<grid_for(n), kBatchThreads, kBatchLdsBytes, st>>>(
+                idx->d_emb, idx->d_bq, n, dim, nq, n, 1, idx->d_btau, nullptr, idx->d_bcnt,
+                reinterpret_cast<Cand32 *>(idx->d_bcand), kCandCap, idx->d_dense_src, allow);
+        else
+            dense_batched_kernel<false, false><<<grid_for(n), kBatchThreads, kBatchLdsBytes, st>>>(
+                idx->d_emb, idx->d_bq, n, dim, nq, n, 1, idx->d_btau, nullptr, idx->d_bcnt,
+                reinterpret_cast<Cand32 *>(idx->d_bcand), kCandCap, nullptr, nullptr);
+        ANRAG_HIP(hipGetLastError());
+    }
+    {
+        LaunchTimer t(idx, ANRAG_KERNEL_SELECT, st);
+        batched_select_kernel<<<nq, 64, 0, st>>>(reinterpret_cast<const Cand32 *>(idx->d_bcand), idx->d_bcnt, kCandCap, k,
+                                                 idx->d_dense_doc, idx->dense_doc_base, d_out, d_flag ? d_flag : idx->d_bflag);
+        ANRAG_HIP(hipGetLastError());
+    }
+    return ANRAG_OK;
+}
+
+}  // namespace anrag

@@ -132,6 +132,17 @@ int anrag_dense_search(anrag_index *idx, const float *queries, int32_t n_queries
 int anrag_dense_search_device(anrag_index *idx, const float *d_queries, int32_t n_queries,
                               int32_t k, const uint32_t *d_allow_bits, anrag_candidate *d_out);
 
+/* K2: up to 256 queries in ONE pass over the corpus on the fp32 matrix cores
+ * (v_mfma_f32_32x32x2_f32: exact f32 products and sums, no bf16 rounding), exact
+ * top-k through a sampled-threshold filter (dense_batched.hip).  All operands in
+ * HBM, primary stream, no host sync.  d_flag[q] = 0, or -1 when query q's
+ * survivor list overflowed and the caller must redo it with
+ * anrag_dense_search_device (anrag_dense_search does this by itself and picks
+ * this path on its own for n_queries >= 16 on corpora of >= 65536 rows). */
+int anrag_dense_search_batch_device(anrag_index *idx, const float *d_queries, int32_t n_queries,
+                                    int32_t k, const uint32_t *d_allow_bits, anrag_candidate *d_out,
+                                    int32_t *d_flag);
+
 /* All N scores of one query (what search_engine.py:81 materialises), for tests
  * and for callers that post-process scores themselves.  out: host, n_rows fp32. */
 int anrag_dense_scores(anrag_index *idx, const float *query, float *out_scores);
