@@ -1,0 +1,52 @@
+"""GPU: Recall@10 on data/NICEQA.csv over the stand-in corpus must EQUAL the CPU reference path's
+(BASELINE.json: "Recall@10 equal to the CPU reference on data/NICEQA.csv"), and the top-10 id lists must be
+identical (the stand-in embeddings are sparse hashed BoW: exact dense ties are possible, the canonical oracle
+uses the same (score desc, row asc) rule)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_niceqa_recall_equal_to_cpu_reference():
+    from oracle import ref_search
+    from oracle.ref_bm25 import CsrBM25
+    from helpers import assert_ranking_matches
+    from anrag import niceqa
+    from anrag.bm25_index import Bm25Index
+    from anrag.index import Index
+
+    data = niceqa.load_standin(os.path.join(GOLD, "suggested_queries_bm25_preprocessed.json.gz"),
+                               os.path.join(GOLD, "NICEQA.csv"))
+    assert len(data["ids"]) == 9609 and len(data["questions"]) == 70
+    from oracle.niceqa_ref import cpu_ranked_ids
+
+    gpu = niceqa.gpu_ranked_ids(data)
+    cpu = cpu_ranked_ids(data, *niceqa.encode_questions(data))
+    r_gpu, r_cpu = niceqa.recall_at_10(data, gpu), niceqa.recall_at_10(data, cpu)
+    assert r_gpu == r_cpu, (r_gpu, r_cpu)          # the acceptance criterion
+    assert r_gpu["with_gold_chunk"] >= 60
+    print("NICEQA stand-in:", r_gpu, " identical top-10 lists:", sum(a == b for a, b in zip(gpu, cpu)), "/ 70")
+    # The hashed-BoW stand-in vectors are sparse small integers / norm: many rows have mathematically EQUAL dot
+    # products that differ in the last fp32 bit between BLAS and the device's summation order, so a few lists
+    # reorder inside such near-ties.  Pin the two halves separately:
+    #  (a) the device's dense ranking equals numpy's modulo groups closer than the 1e-4 bar;
+    #  (b) given the device's dense ranking, BM25 + fusion + top-n are exact.
+    bm = CsrBM25(data["tokens"], k1=1.7, b=0.83, epsilon=0.05)
+    bi = Bm25Index(data["tokens"], k1=1.7, b=0.83, epsilon=0.05)
+    qv, qt = niceqa.encode_questions(data)
+    with Index(0) as idx:
+        idx.dense_load(data["embeddings"])
+        for qi, (v, t) in enumerate(zip(qv, qt)):
+            doc, score, cnt = idx.dense_search(v, 25)
+            full = ref_search.dense_scores(v, data["embeddings"])
+            rows, sims = ref_search.similarity_search_with_embedding(v, data["embeddings"], None, 25, None, canonical=True)
+            assert_ranking_matches(rows, sims, doc[0], score[0], 1e-4, full, f"niceqa q{qi}")
+            lists = [([data["ids"][r] for r in doc[0].tolist()], "dense")]
+            if t:
+                lists.append(([data["ids"][r] for r in ref_search.canonical_topk(bm.get_scores(t), 25)], "BM25"))
+            fused = ref_search.weighted_reciprocal_rank_fusion(lists, {"dense": 5.0, "BM25": 1.0}, 40)[:10]
+            assert gpu[qi] == [i for i, _ in fused], qi
