@@ -200,7 +200,6 @@ int anrag_index_create(int device, anrag_index **out) {
     for (int b = 0; b < 2 && e == hipSuccess; ++b) {
         e = hipEventCreateWithFlags(&idx->ev_scan[b], hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&idx->ev_bm25[b], hipEventDisableTiming);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&idx->ev_merged[b], hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&idx->ev_fused[b], hipEventDisableTiming);
     }
     if (e != hipSuccess) {
@@ -247,7 +246,7 @@ int anrag_index_destroy(anrag_index *idx) {
         if (idx->ev_fork) (void)hipEventDestroy(idx->ev_fork);
         if (idx->ev_join) (void)hipEventDestroy(idx->ev_join);
         for (int b = 0; b < 2; ++b) {
-            hipEvent_t evs[] = {idx->ev_scan[b], idx->ev_bm25[b], idx->ev_merged[b], idx->ev_fused[b]};
+            hipEvent_t evs[] = {idx->ev_scan[b], idx->ev_bm25[b], idx->ev_fused[b]};
             for (hipEvent_t ev : evs)
                 if (ev) (void)hipEventDestroy(ev);
         }
@@ -624,15 +623,14 @@ int anrag_wrrf_device(anrag_index *idx, const anrag_candidate *d_dense, int32_t 
 
 // ------------------------------------------------------------------ fused hybrid query
 // dense on `primary`, BM25 on `secondary`, WRRF on `primary` after the join; nothing syncs the host.
-// One hybrid query through the three-stream pipeline (no host sync):
-//   primary    scan(b)                                               -> block lists, set b
-//   secondary  BM25 + partition-list merge                           -> cand[b][k..2k)
-//   fusion     dense block-list merge -> cand[b][0..k); then `tail`  (WRRF, or the copy-out of both lists)
-// b = sequence number & 1.  Back-to-back queries keep the scans adjacent on `primary`; everything else of
-// query i runs under the scan of query i+1.
-enum HybridTail { kTailFuse, kTailCandidates };
-
-static int hybrid_enqueue(anrag_index *idx, HybridTail tail, const float *d_query, const int32_t *d_terms,
+// One hybrid query through the stream pipeline (no host sync), THREE launches:
+//   primary    K1 scan                      -> dense block lists, set b
+//   secondary  K3 BM25                      -> BM25 partition lists
+//   tail       (fused: secondary; candidates: fusion stream) waits for the scan, then ONE kernel merges both
+//              list sets and either fuses (WRRF + top-n -> d_out) or writes both candidate lists to d_out
+// b = sequence number & 1: the dense block lists are double-buffered, so back-to-back queries keep the scans
+// adjacent on `primary` and everything else of query i runs under the scan of query i+1.
+static int hybrid_enqueue(anrag_index *idx, TailMode tail, const float *d_query, const int32_t *d_terms,
                           int32_t n_terms, int32_t k, double w_dense, double w_bm25, double wrrf_k, int32_t top_n,
                           const uint32_t *d_allow_dense, const uint32_t *d_allow_bm25, anrag_candidate *d_out,
                           int32_t *d_count) {
@@ -644,45 +642,26 @@ static int hybrid_enqueue(anrag_index *idx, HybridTail tail, const float *d_quer
     const bool reuse = idx->hyb_seq >= 2;
     idx->hyb_seq++;
     idx->hyb_outstanding = true;
-    anrag_candidate *cand = idx->d_cand_a + (int64_t)b * 2 * ANRAG_FUSED_K_MAX;
-    anrag_candidate *dense_out = cand, *bm25_out = cand + k;
-    int rc, grid = 0;
+    int rc;
     if (use_dense) {
-        if (reuse) ANRAG_HIP(hipStreamWaitEvent(P, idx->ev_merged[b], 0));  // block-list set b is free again
-        if ((rc = launch_dense_scan(idx, P, d_query, k, d_allow_dense, nullptr, b, &grid))) return rc;
+        if (reuse) ANRAG_HIP(hipStreamWaitEvent(P, idx->ev_fused[b], 0));  // the tail two queries back has read set b
+        if ((rc = launch_dense_scan(idx, P, d_query, k, d_allow_dense, nullptr, b))) return rc;
         ANRAG_HIP(hipEventRecord(idx->ev_scan[b], P));
     }
+    hipStream_t T = tail == kTailFuse ? S : F;
     if (use_bm25) {
-        if (reuse) ANRAG_HIP(hipStreamWaitEvent(S, idx->ev_fused[b], 0));  // cand[b] is free again
-        if ((rc = launch_bm25(idx, S, d_terms, n_terms, k, d_allow_bm25, bm25_out, nullptr))) return rc;
-        ANRAG_HIP(hipEventRecord(idx->ev_bm25[b], S));
-    }
-    if (use_dense) {
-        ANRAG_HIP(hipStreamWaitEvent(F, idx->ev_scan[b], 0));
-        if ((rc = launch_dense_merge(idx, F, grid, k, b, dense_out))) return rc;
-    }
-    ANRAG_HIP(hipEventRecord(idx->ev_merged[b], F));
-    if (use_bm25) ANRAG_HIP(hipStreamWaitEvent(F, idx->ev_bm25[b], 0));
-    if (tail == kTailFuse) {
-        int32_t off[3] = {0, 0, 0};
-        double w[2] = {0, 0};
-        int n_lists = 0;
-        const anrag_candidate *first = use_dense ? dense_out : bm25_out;
-        if (use_dense) {
-            w[n_lists] = w_dense;
-            off[n_lists + 1] = off[n_lists] + k;
-            ++n_lists;
+        // the BM25 partition lists are single-buffered: this K3 must not start before the previous tail read them
+        if (T != S && idx->hyb_seq >= 2) ANRAG_HIP(hipStreamWaitEvent(S, idx->ev_fused[b ^ 1], 0));
+        if ((rc = launch_bm25_lists(idx, S, d_terms, n_terms, k, d_allow_bm25, nullptr))) return rc;
+        if (T != S) {
+            ANRAG_HIP(hipEventRecord(idx->ev_bm25[b], S));
+            ANRAG_HIP(hipStreamWaitEvent(T, idx->ev_bm25[b], 0));
         }
-        if (use_bm25) {
-            w[n_lists] = w_bm25;
-            off[n_lists + 1] = off[n_lists] + k;
-            ++n_lists;
-        }
-        if ((rc = launch_wrrf(idx, F, nullptr, first, off, w, n_lists, wrrf_k, top_n, d_out, d_count))) return rc;
-    } else {
-        ANRAG_HIP(hipMemcpyAsync(d_out, cand, (size_t)2 * k * sizeof(anrag_candidate), hipMemcpyDeviceToDevice, F));
     }
-    ANRAG_HIP(hipEventRecord(idx->ev_fused[b], F));
+    if (use_dense) ANRAG_HIP(hipStreamWaitEvent(T, idx->ev_scan[b], 0));
+    if ((rc = launch_tail(idx, T, b, use_dense, use_bm25, k, tail, w_dense, w_bm25, wrrf_k, top_n, d_out, d_count)))
+        return rc;
+    ANRAG_HIP(hipEventRecord(idx->ev_fused[b], T));
     return ANRAG_OK;
 }
 
@@ -724,7 +703,7 @@ int anrag_hybrid_search(anrag_index *idx, const float *query, const int32_t *ter
                   "a source filter needs source ids");
     int rc;
     if ((rc = settle_pipeline(idx))) return rc;  // the staging buffers below are single
-    hipStream_t P = idx->primary, S = idx->secondary, F = idx->fusion;
+    hipStream_t P = idx->primary, S = idx->secondary;
     if ((rc = ensure_common_workspace(idx))) return rc;
     if ((rc = ensure_wrrf_scratch(idx, 4096))) return rc;
     char *pin = static_cast<char *>(idx->h_pinned);
@@ -744,9 +723,10 @@ int anrag_hybrid_search(anrag_index *idx, const float *query, const int32_t *ter
         return rc;
     anrag_candidate *h_cand = reinterpret_cast<anrag_candidate *>(pin + 16384);
     int32_t *h_cnt = reinterpret_cast<int32_t *>(pin + 16384 + 4096);
-    ANRAG_HIP(hipMemcpyAsync(h_cand, idx->d_w_out, (size_t)top_n * sizeof(anrag_candidate), hipMemcpyDeviceToHost, F));
-    ANRAG_HIP(hipMemcpyAsync(h_cnt, idx->d_w_count, sizeof(int32_t), hipMemcpyDeviceToHost, F));
     if ((rc = sync_all(idx))) return rc;
+    ANRAG_HIP(hipMemcpyAsync(h_cand, idx->d_w_out, (size_t)top_n * sizeof(anrag_candidate), hipMemcpyDeviceToHost, P));
+    ANRAG_HIP(hipMemcpyAsync(h_cnt, idx->d_w_count, sizeof(int32_t), hipMemcpyDeviceToHost, P));
+    ANRAG_HIP(hipStreamSynchronize(P));
     const int32_t cnt = std::min(*h_cnt, top_n);
     for (int32_t i = 0; i < cnt; ++i) {
         out_id[i] = h_cand[i].doc;
@@ -766,6 +746,19 @@ int anrag_merge_candidates_device(anrag_index *idx, const anrag_candidate *d_lis
                   ANRAG_FUSED_K_MAX);
     ANRAG_REQUIRE(list_stride >= k, "list_stride %lld < k", (long long)list_stride);
     return launch_merge_candidates(idx, idx->fusion, d_lists, n_lists, k, list_stride, d_out);
+}
+
+int anrag_merge_fuse_device(anrag_index *idx, const anrag_candidate *d_lists, int32_t n_lists, int32_t k,
+                            int64_t list_stride, double w_dense, double w_bm25, double wrrf_k, int32_t top_n,
+                            anrag_candidate *d_out, int32_t *d_count) {
+    ANRAG_ENTER(idx);
+    ANRAG_REQUIRE(d_lists && d_out && d_count, "NULL operand");
+    ANRAG_REQUIRE(n_lists > 0 && k > 0 && k <= ANRAG_FUSED_K_MAX, "need n_lists > 0 and 1 <= k <= %d",
+                  ANRAG_FUSED_K_MAX);
+    ANRAG_REQUIRE(list_stride >= 2 * (int64_t)k, "list_stride %lld < 2k", (long long)list_stride);
+    ANRAG_REQUIRE(top_n > 0 && top_n <= 2 * ANRAG_FUSED_K_MAX, "top_n %d out of range", top_n);
+    return launch_merge_fuse(idx, idx->fusion, d_lists, n_lists, k, list_stride, w_dense, w_bm25, wrrf_k, top_n, d_out,
+                             d_count);
 }
 
 // ------------------------------------------------------------------ device memory helpers

@@ -22,7 +22,7 @@
 //     workgroup reads only its own slice of the posting list; rare terms are scanned whole (<= 8 KB
 //     of doc ids, L2-resident across the workgroups) and range-checked.
 //   * selection runs on the LDS slice (wave_topk.hpp), zero-score documents included, as the
-//     reference ranks them (:236-243); one sorted list per partition -> merge kernel (select.hip).
+//     reference ranks them (:236-243); one sorted list per partition -> tail kernel (tail.hip).
 #include <algorithm>
 #include <vector>
 
@@ -88,7 +88,7 @@ __global__ __launch_bounds__(kBm25Threads) void bm25_kernel(
     __shared__ uint32_t lds_r[kBm25Waves * kListLen];
     __shared__ uint32_t lds_allow[FILTER ? 2048 : 1];
 
-    const int tid = threadIdx.x, lane = lane_id(), wave = tid / kWave;
+    const int tid = threadIdx.x;
     const int32_t part = blockIdx.x;
     const int64_t lo = (int64_t)part * part_docs;
     const int64_t hi = lo + part_docs < n_docs ? lo + part_docs : n_docs;
@@ -179,9 +179,9 @@ __global__ __launch_bounds__(kBm25Threads) void bm25_kernel(
             top.offer_lanes(ok && top.admits(s, r), s, r);
         }
         block_merge(top, lds_s, lds_r, kBm25Waves);
-        if (wave == 0) {
-            blk_score[blockIdx.x * kListLen + lane] = top.s;
-            blk_row[blockIdx.x * kListLen + lane] = top.r;
+        if (threadIdx.x < kWave) {
+            blk_score[blockIdx.x * kListLen + threadIdx.x] = top.s;
+            blk_row[blockIdx.x * kListLen + threadIdx.x] = top.r;
         }
     }
 }
@@ -338,8 +338,9 @@ int bm25_load(anrag_index *idx, const int64_t *indptr, int64_t n_terms, const in
     return ANRAG_OK;
 }
 
-int launch_bm25(anrag_index *idx, hipStream_t st, const int32_t *d_terms, int32_t n_terms, int32_t k,
-                const uint32_t *d_allow_bits, anrag_candidate *d_out, double *d_scores_out) {
+// K3 only: per-partition lists (or every score) are left in HBM; the tail kernel finishes the top-k
+int launch_bm25_lists(anrag_index *idx, hipStream_t st, const int32_t *d_terms, int32_t n_terms, int32_t k,
+                      const uint32_t *d_allow_bits, double *d_scores_out) {
     const uint32_t *allow = idx->d_bm25_src ? d_allow_bits : nullptr;
     {
         LaunchTimer t(idx, ANRAG_KERNEL_BM25, st);
@@ -356,10 +357,14 @@ int launch_bm25(anrag_index *idx, hipStream_t st, const int32_t *d_terms, int32_
 #undef ANRAG_BM25
         ANRAG_HIP(hipGetLastError());
     }
-    if (!d_scores_out)
-        return launch_merge_block_lists_f64(idx, st, idx->d_blk_score_f64, idx->d_blk_row_b, idx->n_parts, k,
-                                            idx->d_bm25_doc, idx->bm25_doc_base, d_out);
     return ANRAG_OK;
+}
+
+int launch_bm25(anrag_index *idx, hipStream_t st, const int32_t *d_terms, int32_t n_terms, int32_t k,
+                const uint32_t *d_allow_bits, anrag_candidate *d_out, double *d_scores_out) {
+    int rc = launch_bm25_lists(idx, st, d_terms, n_terms, k, d_allow_bits, d_scores_out);
+    if (rc || d_scores_out) return rc;
+    return launch_tail(idx, st, 0, /*dense*/ false, /*bm25*/ true, k, kTailCandidates, 0, 0, 0, 0, d_out, nullptr);
 }
 
 }  // namespace anrag

@@ -60,7 +60,6 @@ struct anrag_index {
     // hybrid pipeline, double-buffered on (query sequence number & 1)
     hipEvent_t ev_scan[2] = {nullptr, nullptr};    // scan of buffer b finished (primary)
     hipEvent_t ev_bm25[2] = {nullptr, nullptr};    // BM25 candidates of buffer b ready (secondary)
-    hipEvent_t ev_merged[2] = {nullptr, nullptr};  // block lists of buffer b consumed (fusion)
     hipEvent_t ev_fused[2] = {nullptr, nullptr};   // candidate slots of buffer b consumed (fusion)
     uint64_t hyb_seq = 0;
     bool hyb_outstanding = false;
@@ -146,11 +145,20 @@ struct LaunchTimer {
 int drain_profile(anrag_index *idx);
 
 // ---- kernel launchers (each enqueues on `stream`, never syncs)
-// scan only: leaves one sorted list per workgroup in block-list set `set`; *out_grid = number of lists
+int dense_scan_grid(const anrag_index *idx);
+// K1 alone: one sorted list per workgroup into block-list set `set` (or every score into d_scores_out, k = 0)
 int launch_dense_scan(anrag_index *idx, hipStream_t stream, const float *d_query, int32_t k,
-                      const uint32_t *d_allow_bits, float *d_scores_out, int set, int *out_grid);
-int launch_dense_merge(anrag_index *idx, hipStream_t stream, int n_lists, int32_t k, int set, anrag_candidate *d_out);
-// scan + merge on one stream (set 0)
+                      const uint32_t *d_allow_bits, float *d_scores_out, int set);
+int launch_bm25_lists(anrag_index *idx, hipStream_t st, const int32_t *d_terms, int32_t n_terms, int32_t k,
+                      const uint32_t *d_allow_bits, double *d_scores_out);
+// Tail of a query, ONE launch (tail.hip): merge the dense block lists of set `set` and/or the BM25 partition
+// lists into per-modality top-k, then either write both lists (kTailCandidates: d_out[0..k) dense,
+// [k..2k) BM25; with one modality only its k records at d_out[0..k)) or fuse them (kTailFuse: WRRF + top_n).
+enum TailMode { kTailFuse = 0, kTailCandidates = 1 };
+int launch_tail(anrag_index *idx, hipStream_t st, int set, bool use_dense, bool use_bm25, int32_t k, TailMode mode,
+                double w_dense, double w_bm25, double wrrf_k, int32_t top_n, anrag_candidate *d_out,
+                int32_t *d_count);
+// K1 + tail on one stream (set 0)
 int launch_dense_topk(anrag_index *idx, hipStream_t stream, const float *d_query, int32_t k,
                       const uint32_t *d_allow_bits, anrag_candidate *d_out, float *d_scores_out);
 // K2: up to 256 queries per pass on the fp32 matrix cores (dense_batched.hip)
@@ -170,12 +178,6 @@ int launch_bm25(anrag_index *idx, hipStream_t stream, const int32_t *d_terms, in
                 const uint32_t *d_allow_bits, anrag_candidate *d_out, double *d_scores_out);
 int bm25_search_large_k(anrag_index *idx, hipStream_t stream, const int32_t *d_terms, int32_t n_terms, int32_t k,
                         const uint32_t *d_allow_bits, int64_t *out_doc, double *out_score, int32_t *out_count);
-int launch_merge_block_lists_f32(anrag_index *idx, hipStream_t st, const float *blk_score, const uint32_t *blk_row,
-                                 int32_t n_lists, int32_t k, const int64_t *doc_of_row, int64_t doc_base,
-                                 anrag_candidate *d_out);
-int launch_merge_block_lists_f64(anrag_index *idx, hipStream_t st, const double *blk_score, const uint32_t *blk_row,
-                                 int32_t n_lists, int32_t k, const int64_t *doc_of_row, int64_t doc_base,
-                                 anrag_candidate *d_out);
 // WRRF over `n_lists` id lists laid out back to back in d_ids or d_cands (list l = [h_off[l], h_off[l+1])); entries
 // with id < 0 are padding.  Writes min(top_n, distinct) records to d_out and the count to *d_count.
 int ensure_wrrf_scratch(anrag_index *idx, int64_t n_entries);
@@ -183,6 +185,9 @@ void free_wrrf_scratch(anrag_index *idx);
 int launch_wrrf(anrag_index *idx, hipStream_t st, const int64_t *d_ids, const anrag_candidate *d_cands,
                 const int32_t *h_off, const double *h_weight, int32_t n_lists, double k, int32_t top_n,
                 anrag_candidate *d_out, int32_t *d_count);
+int launch_merge_fuse(anrag_index *idx, hipStream_t st, const anrag_candidate *d_lists, int32_t n_lists, int32_t k,
+                      int64_t list_stride, double w_dense, double w_bm25, double wrrf_k, int32_t top_n,
+                      anrag_candidate *d_out, int32_t *d_count);
 int launch_merge_candidates(anrag_index *idx, hipStream_t stream, const anrag_candidate *d_lists,
                             int32_t n_lists, int32_t k, int64_t list_stride, anrag_candidate *d_out);
 

@@ -13,7 +13,7 @@
 //     unrolls = 96-192 KiB in flight lose 3-6 %, and they starve co-running kernels: profiles/);
 //   * the query slice of each lane lives in registers (CH float4), staged once per wave;
 //   * G-lane butterfly reduction, then the wave's register top-k (wave_topk.hpp);
-//   * per-workgroup LDS tree merge -> one sorted list per workgroup -> merge kernel (select.hip).
+//   * per-workgroup LDS tree merge -> one sorted list per workgroup -> tail kernel (tail.hip).
 //   * the 6-step lane reduction is DPP row ops (no LDS traffic in the streaming loop).
 #include "common.hpp"
 #include "wave_topk.hpp"
@@ -165,6 +165,14 @@ __global__ __launch_bounds__(kScanThreads) void dense_scan_topk_generic_kernel(
     }
 }
 
+int dense_scan_grid(const anrag_index *idx) {
+    int grid = idx->n_cus < kMaxScanBlocks ? idx->n_cus : kMaxScanBlocks;
+    // small corpora: no more workgroups than there are wave-iterations of work
+    const int64_t need = (idx->n_rows + kScanWaves * 4 - 1) / (kScanWaves * 4);
+    if (need < grid) grid = (int)(need > 0 ? need : 1);
+    return grid;
+}
+
 template <int G, int CH>
 static void launch_scan(int grid, hipStream_t st, const anrag_index *idx, const float *q, int32_t k,
                         const uint32_t *allow, float *scores_out, float *blk_s, uint32_t *blk_r) {
@@ -181,17 +189,12 @@ static void launch_scan(int grid, hipStream_t st, const anrag_index *idx, const 
 }
 
 int launch_dense_scan(anrag_index *idx, hipStream_t st, const float *d_query, int32_t k,
-                      const uint32_t *d_allow_bits, float *d_scores_out, int set, int *out_grid) {
+                      const uint32_t *d_allow_bits, float *d_scores_out, int set) {
     const int64_t n = idx->n_rows;
     float *blk_s = idx->d_blk_score_f32 + (int64_t)set * kMaxScanBlocks * kListLen;
     uint32_t *blk_r = idx->d_blk_row_a + (int64_t)set * kMaxScanBlocks * kListLen;
     const int d = idx->dim;
-    int grid = idx->n_cus < kMaxScanBlocks ? idx->n_cus : kMaxScanBlocks;
-    {
-        // small corpora: no more workgroups than there are wave-iterations of work
-        const int64_t need = (n + kScanWaves * 4 - 1) / (kScanWaves * 4);
-        if (need < grid) grid = (int)(need > 0 ? need : 1);
-    }
+    const int grid = dense_scan_grid(idx);
     const uint32_t *allow = (idx->d_dense_src != nullptr) ? d_allow_bits : nullptr;
     {
         LaunchTimer t(idx, ANRAG_KERNEL_DENSE_SCAN, st);
@@ -231,23 +234,14 @@ int launch_dense_scan(anrag_index *idx, hipStream_t st, const float *d_query, in
                                                                           d_scores_out);
         ANRAG_HIP(hipGetLastError());
     }
-    *out_grid = grid;
     return ANRAG_OK;
-}
-
-int launch_dense_merge(anrag_index *idx, hipStream_t st, int n_lists, int32_t k, int set, anrag_candidate *d_out) {
-    return launch_merge_block_lists_f32(idx, st, idx->d_blk_score_f32 + (int64_t)set * kMaxScanBlocks * kListLen,
-                                        idx->d_blk_row_a + (int64_t)set * kMaxScanBlocks * kListLen, n_lists, k,
-                                        idx->d_dense_doc, idx->dense_doc_base, d_out);
 }
 
 int launch_dense_topk(anrag_index *idx, hipStream_t st, const float *d_query, int32_t k,
                       const uint32_t *d_allow_bits, anrag_candidate *d_out, float *d_scores_out) {
-    int grid = 0;
-    int rc = launch_dense_scan(idx, st, d_query, k, d_allow_bits, d_scores_out, 0, &grid);
-    if (rc) return rc;
-    if (k > 0) return launch_dense_merge(idx, st, grid, k, 0, d_out);
-    return ANRAG_OK;
+    int rc = launch_dense_scan(idx, st, d_query, k, d_allow_bits, d_scores_out, 0);
+    if (rc || k <= 0) return rc;
+    return launch_tail(idx, st, 0, /*dense*/ true, /*bm25*/ false, k, kTailCandidates, 0, 0, 0, 0, d_out, nullptr);
 }
 
 }  // namespace anrag

@@ -173,4 +173,53 @@ __device__ __forceinline__ void block_merge(WaveTopK<S> &t, S *lds_s, uint32_t *
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Merge the sorted per-workgroup lists K1 / K3 leave in HBM ([n_lists][64] score + local row) into `top`.
+// Called by the `n_waves` waves of a group (wave_in_group = 0..n_waves-1), each taking every n_waves-th
+// chunk of 64 lists: lane <-> list.  A lane first pulls kPre entries of its list in ONE batch of independent
+// loads (the dependent HBM round trips are what this costs, not the arithmetic), then rounds: round j
+// offers every still-live list's j-th entry; a list drops out at its first loser (it is sorted).
+template <typename S>
+__device__ __forceinline__ void merge_lists(WaveTopK<S> &top, const S *__restrict__ blk_score,
+                                            const uint32_t *__restrict__ blk_row, int32_t n_lists, int32_t k,
+                                            int wave_in_group, int n_waves) {
+    constexpr int kPre = 4;
+    const int lane = lane_id();
+    for (int l0 = wave_in_group * kWave; l0 < n_lists; l0 += n_waves * kWave) {
+        const int list = l0 + lane;
+        bool live = list < n_lists;
+        const S *ps = blk_score + (int64_t)(live ? list : 0) * kListLen;
+        const uint32_t *pr = blk_row + (int64_t)(live ? list : 0) * kListLen;
+        S es[kPre];
+        uint32_t er[kPre];
+#pragma unroll
+        for (int j = 0; j < kPre; ++j) {
+            es[j] = (live && j < k) ? ps[j] : neg_inf<S>();
+            er[j] = (live && j < k) ? pr[j] : kNoRow;
+        }
+        bool done = false;
+#pragma unroll
+        for (int j = 0; j < kPre; ++j) {
+            if (!done) {
+                const bool cand = live && er[j] != kNoRow && top.admits(es[j], er[j]);
+                if (__ballot(cand) == 0) {
+                    done = true;
+                } else {
+                    top.offer_lanes(cand, es[j], er[j]);
+                    live = cand && !beats(top.thr_s, top.thr_r, es[j], er[j]);  // pushed out again: exhausted
+                }
+            }
+        }
+        if (done) continue;
+        for (int j = kPre; j < k; ++j) {  // rare: one list holds more than kPre winners
+            const S cs = live ? ps[j] : neg_inf<S>();
+            const uint32_t cr = live ? pr[j] : kNoRow;
+            const bool cand = live && cr != kNoRow && top.admits(cs, cr);
+            if (__ballot(cand) == 0) break;
+            top.offer_lanes(cand, cs, cr);
+            live = cand && !beats(top.thr_s, top.thr_r, cs, cr);
+        }
+    }
+}
+
 }  // namespace anrag

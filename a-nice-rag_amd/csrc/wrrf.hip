@@ -11,6 +11,7 @@
 // outrank it.  Latency-bound; M = sum of list lengths is 2*k <= 128 on the hybrid hot path (one
 // workgroup, everything in LDS) and a few 10^4 in retrieval_eval's full-ranking mode (grid form).
 #include "common.hpp"
+#include "wrrf_block.hpp"
 
 namespace anrag {
 
@@ -32,7 +33,7 @@ __device__ __forceinline__ void wrrf_entry(const int64_t *ids, const anrag_candi
 }
 
 __device__ __forceinline__ bool outranks(double sj, int32_t j, double si, int32_t i) {
-    return sj > si || (sj == si && j < i);
+    return wrrf_outranks(sj, j, si, i);
 }
 
 // M <= 1024: one workgroup, one thread per entry.
@@ -44,45 +45,16 @@ __global__ __launch_bounds__(kWrrfSmall) void wrrf_small_kernel(const int64_t *_
     __shared__ int64_t s_id[kWrrfSmall];
     __shared__ double s_c[kWrrfSmall];
     __shared__ double s_score[kWrrfSmall];
-    __shared__ int32_t s_owner[kWrrfSmall];  // 1 = first entry of its id
+    __shared__ int32_t s_owner[kWrrfSmall];
     __shared__ int32_t s_distinct;
     const int i = threadIdx.x;
-    if (i == 0) s_distinct = 0;
     int64_t id = -1;
     double c = 0.0;
     if (i < m) wrrf_entry(ids, cands, L, i, k, id, c);
     s_id[i] = id;
     s_c[i] = c;
     __syncthreads();
-    bool owner = false;
-    double score = 0.0;
-    if (i < m && id >= 0) {
-        owner = true;
-        for (int j = 0; j < i; ++j)
-            if (s_id[j] == id) {
-                owner = false;
-                break;
-            }
-        if (owner)
-            for (int j = i; j < m; ++j)
-                if (s_id[j] == id) score = score + s_c[j];
-    }
-    s_score[i] = score;
-    s_owner[i] = owner ? 1 : 0;
-    if (owner) atomicAdd(&s_distinct, 1);
-    __syncthreads();
-    if (owner) {
-        int32_t pos = 0;
-        for (int j = 0; j < m; ++j)
-            if (s_owner[j] && outranks(s_score[j], j, score, i)) ++pos;
-        if (pos < top_n) {
-            anrag_candidate r;
-            r.score = score;
-            r.doc = id;
-            out[pos] = r;
-        }
-    }
-    if (i == 0) *out_count = s_distinct < top_n ? s_distinct : top_n;
+    wrrf_in_block(s_id, s_c, s_score, s_owner, &s_distinct, m, top_n, out, out_count);
 }
 
 // ---- grid form for long lists (full-ranking evaluation mode)
@@ -205,7 +177,9 @@ int launch_wrrf(anrag_index *idx, hipStream_t st, const int64_t *d_ids, const an
     const int32_t m = h_off[n_lists];
     LaunchTimer t(idx, ANRAG_KERNEL_WRRF, st);
     if (m <= kWrrfSmall) {
-        wrrf_small_kernel<<<1, kWrrfSmall, 0, st>>>(d_ids, d_cands, L, m, k, top_n, d_out, d_count);
+        int threads = 64;  // one thread per entry: 50 entries on the hybrid hot path
+        while (threads < m) threads <<= 1;
+        wrrf_small_kernel<<<1, threads, 0, st>>>(d_ids, d_cands, L, m, k, top_n, d_out, d_count);
         ANRAG_HIP(hipGetLastError());
         return ANRAG_OK;
     }

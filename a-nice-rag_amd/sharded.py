@@ -11,8 +11,8 @@ Per query, on every rank:
     2. exchange            ONE all-gather of 2k x 16 B per rank (k=25: 800 B) -- latency-bound,
                            nowhere near the 7 x 153 GB/s xGMI links, so it runs on a separate
                            communication stream and overlaps the next query's scan
-    3. replicated merge    G sorted lists -> global top-k per modality (`anrag_merge_candidates_device`)
-    4. fusion              weighted RRF + top-n on global ranks (`anrag_wrrf_device`)
+    3. replicated merge    G sorted lists -> global top-k per modality  } one launch:
+    4. fusion              weighted RRF + top-n on the GLOBAL ranks     } `anrag_merge_fuse_device`
 BM25 statistics (idf, avgdl, N) are GLOBAL and replicated at index build, otherwise shard-local
 scores would differ from the single-index reference.
 
@@ -68,6 +68,13 @@ class HipShardEngine:
         self._nat.check(self._lib.anrag_merge_candidates_device(
             self.aux.handle, lists.data_ptr() + offset * 16, n_lists, k, stride, out.data_ptr()))
 
+    def merge_fuse(self, lists: torch.Tensor, n_lists: int, k: int, stride: int, w_dense: float, w_bm25: float,
+                   wrrf_k: float, top_n: int, out: torch.Tensor, count: torch.Tensor) -> None:
+        """Global tail in one launch: per-modality merge of the gathered lists + WRRF + top-n."""
+        self._nat.check(self._lib.anrag_merge_fuse_device(
+            self.aux.handle, lists.data_ptr(), n_lists, k, stride, w_dense, w_bm25, wrrf_k, top_n, out.data_ptr(),
+            count.data_ptr()))
+
     def fuse(self, dense: torch.Tensor, bm25: torch.Tensor, k: int, w_dense: float, w_bm25: float, wrrf_k: float,
              top_n: int, out: torch.Tensor, count: torch.Tensor) -> None:
         self._nat.check(self._lib.anrag_wrrf_device(
@@ -116,10 +123,14 @@ class ShardedSearcher:
                 dist.all_gather_into_tensor(self.recv[slot].view(-1), self.send[slot].view(-1), group=self.group)
             else:
                 self.recv[slot].view(-1).copy_(self.send[slot].view(-1))
-            eng.merge(self.recv[slot], self.world, k, 2 * k, 0, self.merged[slot][:k])
-            eng.merge(self.recv[slot], self.world, k, 2 * k, k, self.merged[slot][k:])
-            eng.fuse(self.merged[slot][:k], self.merged[slot][k:], k, self.w_dense, self.w_bm25, self.wrrf_k,
-                     self.top_n, self.out[slot], self.count[slot])
+            if hasattr(eng, "merge_fuse"):
+                eng.merge_fuse(self.recv[slot], self.world, k, 2 * k, self.w_dense, self.w_bm25, self.wrrf_k,
+                               self.top_n, self.out[slot], self.count[slot])
+            else:  # engines that only expose the three primitives
+                eng.merge(self.recv[slot], self.world, k, 2 * k, 0, self.merged[slot][:k])
+                eng.merge(self.recv[slot], self.world, k, 2 * k, k, self.merged[slot][k:])
+                eng.fuse(self.merged[slot][:k], self.merged[slot][k:], k, self.w_dense, self.w_bm25, self.wrrf_k,
+                         self.top_n, self.out[slot], self.count[slot])
         self._pending.append(slot)
         return slot
 

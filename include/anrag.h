@@ -87,10 +87,11 @@ int anrag_index_destroy(anrag_index *idx);
 /* Run the index's kernels on caller-owned HIP streams (hipStream_t as void*).
  * NULL = the index's own streams.  Roles:
  *   primary    dense scans (and every non-hybrid entry point)
- *   secondary  the BM25 leg of a hybrid query
- *   fusion     dense list merge, WRRF, anrag_merge_candidates_device,
- *              anrag_wrrf_device; the RESULTS of the *_device hybrid entry points
- *              are complete in fusion-stream order.  Pass the stream a
+ *   secondary  the BM25 leg of a hybrid query and, behind it, the fusion kernel
+ *              of anrag_hybrid_search_device (its results are complete in
+ *              secondary-stream order; anrag_index_sync waits for everything)
+ *   fusion     anrag_merge_candidates_device, anrag_wrrf_device and the
+ *              copy-out of anrag_hybrid_candidates_device.  Pass the stream a
  *              torch.distributed (RCCL) collective will be issued on, e.g. a
  *              torch.cuda.Stream's .cuda_stream, and the collective orders
  *              after the per-shard candidates with no host sync. */
@@ -204,10 +205,11 @@ int anrag_hybrid_search(anrag_index *idx, const float *query, const int32_t *ter
 
 /* Same, operands in HBM, nothing syncs the host: d_out receives min(top_n,
  * distinct ids) records in fused order, *d_count that number, complete in
- * fusion-stream order (anrag_index_sync waits for all three streams).
+ * secondary-stream order (anrag_index_sync waits for all streams).
  * Back-to-back queries pipeline: the scans stay adjacent on the primary stream;
- * BM25, the list merges and the fusion of query i run under the scan of
- * query i+1 (double-buffered internally). */
+ * BM25 and the fusion of query i run under the scan of query i+1 (candidate
+ * slots are double-buffered internally).  Three launches per query: K1 and K3
+ * finish their own top-k (last-workgroup merge), K5 fuses. */
 int anrag_hybrid_search_device(anrag_index *idx, const float *d_query, const int32_t *d_term_ids,
                                int32_t n_terms, int32_t similarity_k, double w_dense,
                                double w_bm25, double wrrf_k, int32_t top_n,
@@ -233,6 +235,15 @@ int anrag_hybrid_candidates_device(anrag_index *idx, const float *d_query,
                                    const int32_t *d_term_ids, int32_t n_terms, int32_t k,
                                    const uint32_t *d_allow_dense_bits,
                                    const uint32_t *d_allow_bm25_bits, anrag_candidate *d_out);
+/* The whole global tail of a sharded query in ONE launch (fusion stream):
+ * d_lists holds one record block per shard, block l at d_lists + l*list_stride,
+ * laid out as anrag_hybrid_candidates_device writes it ([0,k) dense, [k,2k)
+ * BM25).  Per modality merge the n_lists lists into the global top-k, then
+ * weighted RRF on those global ranks + top-n -> d_out / *d_count. */
+int anrag_merge_fuse_device(anrag_index *idx, const anrag_candidate *d_lists, int32_t n_lists,
+                            int32_t k, int64_t list_stride, double w_dense, double w_bm25,
+                            double wrrf_k, int32_t top_n, anrag_candidate *d_out,
+                            int32_t *d_count);
 /* WRRF over two device candidate lists (dense, bm25) -> top_n on the device
  * (fusion stream). */
 int anrag_wrrf_device(anrag_index *idx, const anrag_candidate *d_dense, int32_t n_dense,
