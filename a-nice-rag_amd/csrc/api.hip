@@ -33,6 +33,9 @@ static hipEvent_t take_event(anrag_index *idx) {
 
 LaunchTimer::LaunchTimer(anrag_index *i, int k, hipStream_t s) : idx(i), stream(s), kernel(k) {
     if (!idx->profiling || !((idx->profile_mask >> k) & 1u)) return;
+    // timing events are not free: a bracketed launch cannot start before the marker in front of it retires and
+    // holds back the launch behind it (~10 us per bracket on the stream).  Sample every n-th launch.
+    if (idx->profile_every > 1 && (idx->profile_seen[k]++ % idx->profile_every) != 0) return;
     start = take_event(idx);
     stop = take_event(idx);
     if (start) (void)hipEventRecord(start, stream);
@@ -750,15 +753,16 @@ int anrag_merge_candidates_device(anrag_index *idx, const anrag_candidate *d_lis
 
 int anrag_merge_fuse_device(anrag_index *idx, const anrag_candidate *d_lists, int32_t n_lists, int32_t k,
                             int64_t list_stride, double w_dense, double w_bm25, double wrrf_k, int32_t top_n,
-                            anrag_candidate *d_out, int32_t *d_count) {
+                            int32_t n_queries, anrag_candidate *d_out, int32_t *d_count) {
     ANRAG_ENTER(idx);
     ANRAG_REQUIRE(d_lists && d_out && d_count, "NULL operand");
+    ANRAG_REQUIRE(n_queries >= 1 && n_queries <= 65535, "n_queries %d out of range", n_queries);
     ANRAG_REQUIRE(n_lists > 0 && k > 0 && k <= ANRAG_FUSED_K_MAX, "need n_lists > 0 and 1 <= k <= %d",
                   ANRAG_FUSED_K_MAX);
-    ANRAG_REQUIRE(list_stride >= 2 * (int64_t)k, "list_stride %lld < 2k", (long long)list_stride);
+    ANRAG_REQUIRE(list_stride >= 2 * (int64_t)k * n_queries, "list_stride %lld < 2k * n_queries", (long long)list_stride);
     ANRAG_REQUIRE(top_n > 0 && top_n <= 2 * ANRAG_FUSED_K_MAX, "top_n %d out of range", top_n);
-    return launch_merge_fuse(idx, idx->fusion, d_lists, n_lists, k, list_stride, w_dense, w_bm25, wrrf_k, top_n, d_out,
-                             d_count);
+    return launch_merge_fuse(idx, idx->fusion, d_lists, n_lists, k, list_stride, w_dense, w_bm25, wrrf_k, top_n,
+                             n_queries, d_out, d_count);
 }
 
 // ------------------------------------------------------------------ device memory helpers
@@ -800,6 +804,13 @@ int anrag_profile_enable(anrag_index *idx, uint32_t kernel_mask) {
     }
     idx->profiling = kernel_mask != 0;
     idx->profile_mask = kernel_mask;
+    return ANRAG_OK;
+}
+
+int anrag_profile_set_sampling(anrag_index *idx, int32_t every_n) {
+    ANRAG_ENTER(idx);
+    ANRAG_REQUIRE(every_n >= 1, "every_n must be >= 1");
+    idx->profile_every = (uint32_t)every_n;
     return ANRAG_OK;
 }
 

@@ -124,6 +124,8 @@ struct anrag_index {
     // ---- measurement
     bool profiling = false;
     uint32_t profile_mask = 0xFFFFFFFFu;  // bit i: time kernel id i
+    uint32_t profile_every = 1;           // bracket every n-th launch of a kernel id
+    uint32_t profile_seen[ANRAG_KERNEL_COUNT] = {0};
     std::vector<anrag::ProfSpan> spans;
     std::vector<hipEvent_t> event_pool;
     double prof_ms[ANRAG_KERNEL_COUNT] = {0};
@@ -187,7 +189,7 @@ int launch_wrrf(anrag_index *idx, hipStream_t st, const int64_t *d_ids, const an
                 anrag_candidate *d_out, int32_t *d_count);
 int launch_merge_fuse(anrag_index *idx, hipStream_t st, const anrag_candidate *d_lists, int32_t n_lists, int32_t k,
                       int64_t list_stride, double w_dense, double w_bm25, double wrrf_k, int32_t top_n,
-                      anrag_candidate *d_out, int32_t *d_count);
+                      int32_t n_queries, anrag_candidate *d_out, int32_t *d_count);
 int launch_merge_candidates(anrag_index *idx, hipStream_t stream, const anrag_candidate *d_lists,
                             int32_t n_lists, int32_t k, int64_t list_stride, anrag_candidate *d_out);
 

@@ -89,6 +89,10 @@ __global__ __launch_bounds__(128) void merge_fuse_kernel(const anrag_candidate *
     __shared__ int32_t s_owner[2 * kListLen];
     __shared__ int32_t s_distinct;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;  // wave 0: dense lists, wave 1: BM25 lists
+    // one workgroup per query of the exchanged group: its blocks sit 2k records apart inside a shard's slab
+    lists += (int64_t)blockIdx.x * 2 * k;
+    out += (int64_t)blockIdx.x * top_n;
+    count += blockIdx.x;
     DocTopK top;
     top.init(k);
     for (int li = 0; li < n_lists; ++li) {
@@ -115,9 +119,9 @@ __global__ __launch_bounds__(128) void merge_fuse_kernel(const anrag_candidate *
 
 int launch_merge_fuse(anrag_index *idx, hipStream_t st, const anrag_candidate *d_lists, int32_t n_lists, int32_t k,
                       int64_t list_stride, double w_dense, double w_bm25, double wrrf_k, int32_t top_n,
-                      anrag_candidate *d_out, int32_t *d_count) {
+                      int32_t n_queries, anrag_candidate *d_out, int32_t *d_count) {
     LaunchTimer t(idx, ANRAG_KERNEL_WRRF, st);
-    merge_fuse_kernel<<<1, 128, 0, st>>>(d_lists, n_lists, k, list_stride, w_dense, w_bm25, wrrf_k, top_n, d_out,
+    merge_fuse_kernel<<<n_queries, 128, 0, st>>>(d_lists, n_lists, k, list_stride, w_dense, w_bm25, wrrf_k, top_n, d_out,
                                          d_count);
     ANRAG_HIP(hipGetLastError());
     return ANRAG_OK;

@@ -197,11 +197,13 @@ class Index:
         return out_id[:m], out_score[:m]
 
     # ------------------------------------------------------------------ measurement
-    def profile(self, on, kernels=None) -> None:
-        """Bracket launches with HIP events: on=True times every kernel id, `kernels=[ids]` only those."""
+    def profile(self, on, kernels=None, every: int = 1) -> None:
+        """Bracket launches with HIP events: on=True times every kernel id, `kernels=[ids]` only those,
+        `every=n` only every n-th launch (a bracket costs ~10 us of stream time)."""
         mask = 0
         if on:
             mask = 0xFFFFFFFF if kernels is None else sum(1 << int(k) for k in kernels)
+        nat.check(self._lib.anrag_profile_set_sampling(self.handle, max(1, int(every))))
         nat.check(self._lib.anrag_profile_enable(self.handle, mask))
 
     def profile_reset(self) -> None:

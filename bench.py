@@ -47,6 +47,8 @@ def parse_args():
     ap.add_argument("--workload", choices=["hybrid", "dense", "batched"], default="hybrid",
                     help="hybrid = headline (C3); dense = K1 only (C2-shaped); batched = 256-query MFMA passes (C4)")
     ap.add_argument("--batch", type=int, default=256, help="queries per pass of --workload batched")
+    ap.add_argument("--exchange-group", type=int, default=4,
+                    help="N > 1: in-flight queries that share one all-gather (each is still scanned alone)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-queries", type=int, default=3, help="queries of the bounded CPU sample")
     return ap.parse_args()
@@ -152,7 +154,7 @@ def main():
             raise SystemExit("--workload dense is a single-GPU diagnostic")
         engine = HipShardEngine(idx, device)
         searcher = ShardedSearcher(engine, k=K, top_n=TOPN, w_dense=W_DENSE, w_bm25=W_BM25, wrrf_k=WRRF_K,
-                                   depth=4, device=device)
+                                   depth=4, group=args.exchange_group, device=device)
 
         def step(i):
             qi = i % args.queries
@@ -171,7 +173,9 @@ def main():
     finish()
     # events around the dominant kernel only: bracketing every launch would perturb the pipeline
     main_kernel = nat.KERNEL_DENSE_BATCHED if batched else nat.KERNEL_DENSE_SCAN
-    idx.profile(True, kernels=[main_kernel])
+    # HIP events around the dominant kernel, on every 8th launch: a bracket holds its stream for ~10 us, which
+    # at batch=1 would be charged to every query (measured: 463 -> 452 us/step at 1M rows)
+    idx.profile(True, kernels=[main_kernel], every=1 if batched else 8)
     idx.profile_reset()
     barrier()
     t0 = time.perf_counter()
@@ -226,7 +230,8 @@ def main():
                 "rows": args.rows, "dim": args.dim, "rows_per_gpu": n_local,
                 "postings_per_gpu": (int(post["post_doc"].numel()) if post else 0), "vocab": args.vocab if hybrid else 0,
                 "similarity_k": K, "top_n": TOPN, "wrrf_k": WRRF_K, "weights": [W_DENSE, W_BM25],
-                "sharding": "rows/%d + RCCL all-gather of per-shard top-k" % world if world > 1 else "none",
+                "sharding": ("rows/%d + RCCL all-gather of per-shard top-k, %d queries per all-gather"
+                             % (world, args.exchange_group)) if sharded else "none",
                 "bm25_arith": "f64",
             },
             "roofline": {

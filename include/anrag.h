@@ -235,15 +235,19 @@ int anrag_hybrid_candidates_device(anrag_index *idx, const float *d_query,
                                    const int32_t *d_term_ids, int32_t n_terms, int32_t k,
                                    const uint32_t *d_allow_dense_bits,
                                    const uint32_t *d_allow_bm25_bits, anrag_candidate *d_out);
-/* The whole global tail of a sharded query in ONE launch (fusion stream):
- * d_lists holds one record block per shard, block l at d_lists + l*list_stride,
- * laid out as anrag_hybrid_candidates_device writes it ([0,k) dense, [k,2k)
- * BM25).  Per modality merge the n_lists lists into the global top-k, then
- * weighted RRF on those global ranks + top-n -> d_out / *d_count. */
+/* The whole global tail of a GROUP of sharded queries in ONE launch (fusion
+ * stream).  d_lists is the all-gather receive buffer: shard l's slab starts at
+ * d_lists + l*list_stride and holds n_queries blocks of 2k records, block q as
+ * anrag_hybrid_candidates_device wrote it for query q ([0,k) dense, [k,2k)
+ * BM25).  Per query and modality: merge the n_lists lists into the global
+ * top-k, then weighted RRF on those global ranks + top-n
+ * -> d_out + q*top_n, d_count[q].  Exchanging several in-flight queries per
+ * all-gather amortises the collective's fixed cost (each query is still
+ * scanned on its own: batch = 1 kernels). */
 int anrag_merge_fuse_device(anrag_index *idx, const anrag_candidate *d_lists, int32_t n_lists,
                             int32_t k, int64_t list_stride, double w_dense, double w_bm25,
-                            double wrrf_k, int32_t top_n, anrag_candidate *d_out,
-                            int32_t *d_count);
+                            double wrrf_k, int32_t top_n, int32_t n_queries,
+                            anrag_candidate *d_out, int32_t *d_count);
 /* WRRF over two device candidate lists (dense, bm25) -> top_n on the device
  * (fusion stream). */
 int anrag_wrrf_device(anrag_index *idx, const anrag_candidate *d_dense, int32_t n_dense,
@@ -264,6 +268,10 @@ int anrag_copy_to_host(anrag_index *idx, void *h_dst, const void *d_src, int64_t
  * (waits for the launches) and returns the summed device time and launch count
  * of one kernel id since the last reset. */
 int anrag_profile_enable(anrag_index *idx, uint32_t kernel_mask);
+/* Bracket only every n-th launch of each selected kernel id (default 1 = all).
+ * A bracketed launch costs ~10 us of stream time (it cannot overlap the marker
+ * before it), so a throughput measurement samples. */
+int anrag_profile_set_sampling(anrag_index *idx, int32_t every_n);
 int anrag_profile_reset(anrag_index *idx);
 int anrag_profile_read(anrag_index *idx, int kernel_id, double *out_total_ms, int64_t *out_launches);
 /* Shape facts a caller needs for roofline arithmetic. */

@@ -41,7 +41,8 @@ def test_sharded_pipeline_world1_rccl():
         idx.dense_load(e, doc_id_base=1000)
         idx.bm25_load(bi.indptr, bi.post_doc, bi.post_tf, bi.idf, bi.doc_len, bi.avgdl, bi.k1, bi.b, doc_id_base=1000)
         engine = HipShardEngine(idx, device)
-        searcher = ShardedSearcher(engine, k=k, top_n=top_n, w_dense=5.0, w_bm25=1.0, wrrf_k=40, depth=4, device=device)
+        searcher = ShardedSearcher(engine, k=k, top_n=top_n, w_dense=5.0, w_bm25=1.0, wrrf_k=40, depth=4, group=3,
+                                   device=device)
         rng = np.random.default_rng(3)
         queries, toks_all = [], []
         for i in range(4):
@@ -68,7 +69,7 @@ def test_sharded_pipeline_world1_rccl():
                 assert scores.tolist() == [s for _, s in want]
         # the single-call fused path gives the same answer
         fid, fs = idx.hybrid_search(queries[0], bi.term_ids(toks_all[0]), k, 5.0, 1.0, 40, top_n)
-        ids, scores = searcher.result(0)
+        ids, scores = searcher.result(slots[0])
         assert fid.tolist() == ids.tolist() and fs.tolist() == scores.tolist()
     finally:
         dist.destroy_process_group()

@@ -68,24 +68,23 @@ class OracleShardEngine:
         top = ref_search.canonical_topk(sc, k)
         self._write(out[k:], top + self.lo, sc[top], k)
 
-    def merge(self, lists, n_lists, k, stride, offset, out):
+    def merge_fuse(self, lists, n_lists, k, stride, w_dense, w_bm25, wrrf_k, top_n, n_queries, out, count):
         rec = lists.numpy().reshape(-1, 2)
-        cands = []
-        for l in range(n_lists):
-            for r in rec[l * stride + offset: l * stride + offset + k]:
-                if r[1] >= 0:
-                    cands.append((float(np.int64(r[0]).view(np.float64)), int(r[1])))
-        cands.sort(key=lambda c: (-c[0], c[1]))
-        cands = cands[:k]
-        self._write(out, [c[1] for c in cands], [c[0] for c in cands], k)
-
-    def fuse(self, dense, bm25, k, w_dense, w_bm25, wrrf_k, top_n, out, count):
-        dl = [int(d) for d in dense.numpy()[:, 1] if d >= 0]
-        bl = [int(d) for d in bm25.numpy()[:, 1] if d >= 0]
-        fused = ref_search.weighted_reciprocal_rank_fusion([(dl, "d"), (bl, "b")], {"d": w_dense, "b": w_bm25},
-                                                           int(wrrf_k))[:top_n]
-        self._write(out, [i for i, _ in fused], [s for _, s in fused], top_n)
-        count.fill_(len(fused))
+        for q in range(n_queries):
+            merged = []
+            for leg in range(2):
+                cands = []
+                for l in range(n_lists):
+                    base = l * stride + q * 2 * k + leg * k
+                    for r in rec[base: base + k]:
+                        if r[1] >= 0:
+                            cands.append((float(np.int64(r[0]).view(np.float64)), int(r[1])))
+                cands.sort(key=lambda c: (-c[0], c[1]))
+                merged.append([c[1] for c in cands[:k]])
+            fused = ref_search.weighted_reciprocal_rank_fusion(
+                [(merged[0], "d"), (merged[1], "b")], {"d": w_dense, "b": w_bm25}, int(wrrf_k))[:top_n]
+            self._write(out[q], [i for i, _ in fused], [s for _, s in fused], top_n)
+            count[q] = len(fused)
 
 
 def _worker(rank, world, port, ret):
@@ -101,23 +100,28 @@ def _worker(rank, world, port, ret):
     glob = CsrBM25(corpus, k1=1.7, b=0.83, epsilon=0.05)
     lo, hi = shard_bounds(n, world, rank)
     eng = OracleShardEngine(e[lo:hi], lo, glob, corpus[lo:hi])
-    searcher = ShardedSearcher(eng, k=k, top_n=top_n, w_dense=5.0, w_bm25=1.0, wrrf_k=40, depth=2)
     rng = np.random.default_rng(11)
     ok = True
-    for trial in range(6):
-        target = int(rng.integers(n))
-        q = synth_query(e, 100 + trial, target)
-        toks = [str(t) for t in rng.choice(corpus[target], size=4)]
-        terms = np.array(glob.term_ids(toks), dtype=np.int32)
-        slot = searcher.submit(torch.from_numpy(q), torch.from_numpy(terms), len(terms))
-        searcher.drain()
-        ids, scores = searcher.result(slot)
-        # single-index oracle
-        sims = ref_search.dense_scores(q, e)
-        dl = ref_search.canonical_topk(sims, k).tolist()
-        bl = ref_search.canonical_topk(glob.get_scores(toks), k).tolist()
-        want = ref_search.weighted_reciprocal_rank_fusion([(dl, "d"), (bl, "b")], {"d": 5.0, "b": 1.0}, 40)[:top_n]
-        ok = ok and ids.tolist() == [i for i, _ in want] and scores.tolist() == [s for _, s in want]
+    for group in (1, 3):  # one query per all-gather, and grouped exchanges with a partial last group
+        searcher = ShardedSearcher(eng, k=k, top_n=top_n, w_dense=5.0, w_bm25=1.0, wrrf_k=40, depth=2, group=group)
+        tickets, wants = [], []
+        for trial in range(5):
+            target = int(rng.integers(n))
+            q = synth_query(e, 100 + trial, target)
+            toks = [str(t) for t in rng.choice(corpus[target], size=4)]
+            terms = np.array(glob.term_ids(toks), dtype=np.int32)
+            tickets.append(searcher.submit(torch.from_numpy(q), torch.from_numpy(terms), len(terms)))
+            sims = ref_search.dense_scores(q, e)  # single-index oracle
+            dl = ref_search.canonical_topk(sims, k).tolist()
+            bl = ref_search.canonical_topk(glob.get_scores(toks), k).tolist()
+            wants.append(ref_search.weighted_reciprocal_rank_fusion([(dl, "d"), (bl, "b")], {"d": 5.0, "b": 1.0},
+                                                                    40)[:top_n])
+            if group == 1 or trial == 4 or len(tickets) % (2 * group) == 0:
+                searcher.drain()  # within depth=2 groups: read before the slots are reused
+                for t, want in zip(tickets, wants):
+                    ids, scores = searcher.result(t)
+                    ok = ok and ids.tolist() == [i for i, _ in want] and scores.tolist() == [s for _, s in want]
+                tickets, wants = [], []
     t = torch.tensor([1 if ok else 0])
     dist.all_reduce(t, op=dist.ReduceOp.MIN)
     if rank == 0:
