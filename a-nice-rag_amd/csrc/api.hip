@@ -307,14 +307,14 @@ int anrag_dense_load(anrag_index *idx, const float *embeddings, int64_t n_rows, 
     if ((rc = dev_alloc(idx, &idx->d_emb, n_rows * dim))) return rc;
     idx->n_rows = n_rows;
     idx->dim = dim;
-    ANRAG_HIP(hipMemcpy(idx->d_emb, embeddings, (size_t)n_rows * dim * sizeof(float), hipMemcpyDefault));
+    ANRAG_HIP(copy_in(idx, idx->d_emb, embeddings, (size_t)n_rows * dim * sizeof(float)));
     if (source_id) {
         if ((rc = dev_alloc(idx, &idx->d_dense_src, n_rows))) return rc;
-        ANRAG_HIP(hipMemcpy(idx->d_dense_src, source_id, (size_t)n_rows * sizeof(uint16_t), hipMemcpyDefault));
+        ANRAG_HIP(copy_in(idx, idx->d_dense_src, source_id, (size_t)n_rows * sizeof(uint16_t)));
     }
     if (doc_id) {
         if ((rc = dev_alloc(idx, &idx->d_dense_doc, n_rows))) return rc;
-        ANRAG_HIP(hipMemcpy(idx->d_dense_doc, doc_id, (size_t)n_rows * sizeof(int64_t), hipMemcpyDefault));
+        ANRAG_HIP(copy_in(idx, idx->d_dense_doc, doc_id, (size_t)n_rows * sizeof(int64_t)));
     }
     idx->dense_doc_base = doc_id_base;
     if (!idx->d_blk_score_f32) {

@@ -261,7 +261,7 @@ int bm25_load(anrag_index *idx, const int64_t *indptr, int64_t n_terms, const in
     ANRAG_HIP(hipMemcpy(idx->d_indptr, indptr, (size_t)(n_terms + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
     ANRAG_HIP(hipMemcpy(idx->d_idf, idf, (size_t)n_terms * sizeof(double), hipMemcpyHostToDevice));
     if (n_postings > 0)
-        ANRAG_HIP(hipMemcpy(idx->d_post_doc, post_doc, (size_t)n_postings * sizeof(int32_t), hipMemcpyDefault));
+        ANRAG_HIP(copy_in(idx, idx->d_post_doc, post_doc, (size_t)n_postings * sizeof(int32_t)));
 
     // impacts: tf and doc_len are only needed here
     {
@@ -274,7 +274,7 @@ int bm25_load(anrag_index *idx, const int64_t *indptr, int64_t n_terms, const in
             return ANRAG_ERR_NOMEM;
         }
         e = hipMemcpy(d_dl, doc_len, (size_t)n_docs * 4, hipMemcpyHostToDevice);
-        if (e == hipSuccess && n_postings > 0) e = hipMemcpy(d_tf, post_tf, (size_t)n_postings * 4, hipMemcpyDefault);
+        if (e == hipSuccess && n_postings > 0) e = copy_in(idx, d_tf, post_tf, (size_t)n_postings * 4);
         if (e == hipSuccess && n_postings > 0) {
             const int64_t blocks = (n_postings + 255) / 256;
             bm25_impact_kernel<<<(unsigned)blocks, 256, 0, idx->primary>>>(idx->d_post_doc, d_tf, d_dl, n_postings, k1,
@@ -321,11 +321,11 @@ int bm25_load(anrag_index *idx, const int64_t *indptr, int64_t n_terms, const in
     }
     if (source_id) {
         if ((rc = bm25_alloc(idx, &idx->d_bm25_src, n_docs))) return rc;
-        ANRAG_HIP(hipMemcpy(idx->d_bm25_src, source_id, (size_t)n_docs * sizeof(uint16_t), hipMemcpyDefault));
+        ANRAG_HIP(copy_in(idx, idx->d_bm25_src, source_id, (size_t)n_docs * sizeof(uint16_t)));
     }
     if (doc_id) {
         if ((rc = bm25_alloc(idx, &idx->d_bm25_doc, n_docs))) return rc;
-        ANRAG_HIP(hipMemcpy(idx->d_bm25_doc, doc_id, (size_t)n_docs * sizeof(int64_t), hipMemcpyDefault));
+        ANRAG_HIP(copy_in(idx, idx->d_bm25_doc, doc_id, (size_t)n_docs * sizeof(int64_t)));
     }
     // per-partition candidate lists
     if (idx->d_blk_score_f64) (void)hipFree(idx->d_blk_score_f64);

@@ -134,6 +134,15 @@ struct anrag_index {
 
 namespace anrag {
 
+// Upload helper for operands that may already live in HBM (torch tensors): a device-to-device hipMemcpy is NOT
+// ordered against the index's non-blocking streams and may return before it has finished, so copy on the
+// primary stream and wait for it.  (The caller must have synchronised whatever produced a device operand.)
+inline hipError_t copy_in(anrag_index *idx, void *dst, const void *src, size_t bytes) {
+    hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, idx->primary);
+    if (e != hipSuccess) return e;
+    return hipStreamSynchronize(idx->primary);
+}
+
 // Bracket a launch with events when profiling is on.
 struct LaunchTimer {
     anrag_index *idx;

@@ -49,8 +49,6 @@ def test_golden_dense_vectors(Index):
         with Index(0) as idx:
             idx.dense_load(e, source_id=sid)
             for c in group:
-                if c["k"] > 64:
-                    continue  # large-k path: test_gpu_large_k.py
                 q = e[c["dup_of"]].copy() if dups else synth_query(e, c["query_seed"], c["query_row"])
                 allow = _allow(distinct, c["filter"]) if c["filter"] else None
                 doc, score, count = idx.dense_search(q.astype(np.float32), c["k"], allow)
