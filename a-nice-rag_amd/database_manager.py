@@ -215,6 +215,22 @@ class DatabaseManager:
             if conn is not None:
                 conn.close()
 
+    def load_flat_index(self, path: str, model_name: str = None):
+        """A flat, mmap-able index directory (anrag.index_io.save_flat_index) -> the same objects the two loaders
+        above return: (DataFrame with HBM handle, (bm25 proxy, sections, section_ids) or None)."""
+        from . import index_io
+
+        meta, emb, stats = index_io.load_flat_index(path)
+        df = pd.DataFrame({"id": meta["ids"], "document": [""] * len(meta["ids"]), "source": meta["sources"],
+                           "embedding": list(emb), "url": [None] * len(meta["ids"])})
+        DenseHandle(np.asarray(emb), meta["sources"]).bind(df)
+        bm25_tuple = None
+        if stats is not None:
+            m = meta["bm25"]
+            sections = [index_io.Section("", {"id": i, "source": s}) for i, s in zip(m["section_ids"], m["section_sources"])]
+            bm25_tuple = (Bm25Proxy(stats, m["section_sources"]), sections, m["section_ids"])
+        return df, bm25_tuple
+
     def load_bm25_from_pickle(self, filepath: str) -> Tuple:
         """database_manager.py:77-99: `{"bm25", "sections", "section_ids"}` pickle (written by
         processing/bm25_search.py:82-93) -> (bm25, sections, section_ids); the bm25 object is replaced by
