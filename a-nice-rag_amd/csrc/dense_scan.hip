@@ -7,10 +7,11 @@
 // Mapping (wave64):
 //   * G lanes share one row (G = 64 when D % 256 == 0: a whole wave reads 1 KiB of one row per
 //     global_load_dwordx4; D = 384 uses G = 32, i.e. two rows per wave-load, 512 B each);
-//   * a wave keeps R row-groups in flight per iteration (R*CH dwordx4 loads per lane issued
-//     before the first use); ONE 4-wave workgroup per CU strides the matrix: 4 waves x 12 KiB =
-//     48 KiB in flight per CU measured best on MI355X (7.0 TB/s at 1M x 768; 8/16 waves or deeper
-//     unrolls = 96-192 KiB in flight lose 3-6 %, and they starve co-running kernels: profiles/);
+//   * a wave works in batches of R row-groups (R*CH ~ 6 dwordx4 loads per lane), software-pipelined over
+//     two register sets so that the next batch is in flight while this one is reduced; ONE 4-wave
+//     workgroup per CU strides the matrix: 24-48 KiB in flight per CU measured best on MI355X
+//     (7.05 TB/s at 1M x 768; 8/16 waves or deeper unrolls = 96-192 KiB in flight lose 3-6 % and starve
+//     co-running kernels: profiles/r01_scan_config_sweep.txt);
 //   * the query slice of each lane lives in registers (CH float4), staged once per wave;
 //   * G-lane butterfly reduction, then the wave's register top-k (wave_topk.hpp);
 //   * per-workgroup LDS tree merge -> one sorted list per workgroup -> tail kernel (tail.hip).
@@ -87,36 +88,57 @@ __global__ __launch_bounds__(THREADS) void dense_scan_kernel(
     WaveTopK<float> top;
     top.init(SCORES ? 1 : k);
 
-    const int64_t total_waves = (int64_t)gridDim.x * WAVES;
-    const int64_t gwave = (int64_t)blockIdx.x * WAVES + wave;
-    for (int64_t base = gwave * RW; base < n_rows; base += total_waves * RW) {
+    // One batch = R row-groups of this wave: R*CH dwordx4 loads per lane.  The loop is software-pipelined over
+    // two register sets: the loads of batch i+1 are issued BEFORE batch i is reduced, so the wave always has
+    // loads in flight (a pure-read kernel of this geometry reaches 7.0-7.4 TB/s on MI355X:
+    // profiles/r01_hbm_read_ceiling.txt).
+    struct Batch {
         f32x4 v[R][CH];
-        int64_t row[R];
         uint32_t sid[R];
+    };
+    auto issue = [&](int64_t base, Batch &bt) {
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            row[r] = base + r * GROUPS + grp;
-            const int64_t rc = row[r] < n_rows ? row[r] : n_rows - 1;  // clamp: tail lanes re-read the last row
-            if constexpr (FILTER) sid[r] = src[rc];                    // issued ahead of the row data
+            const int64_t row = base + r * GROUPS + grp;
+            const int64_t rc = row < n_rows ? row : n_rows - 1;  // clamp: tail lanes re-read the last row
+            if constexpr (FILTER) bt.sid[r] = src[rc];           // issued ahead of the row data
             const f32x4 *p = ev + rc * row_f4 + sub;
 #pragma unroll
-            for (int c = 0; c < CH; ++c) v[r][c] = __builtin_nontemporal_load(p + c * G);
+            for (int c = 0; c < CH; ++c) bt.v[r][c] = __builtin_nontemporal_load(p + c * G);
         }
+    };
+    auto reduce = [&](int64_t base, const Batch &bt) {
 #pragma unroll
         for (int r = 0; r < R; ++r) {
+            const int64_t row = base + r * GROUPS + grp;
             float acc = 0.f;
 #pragma unroll
-            for (int c = 0; c < CH; ++c) acc = dot4(v[r][c], q[c], acc);
+            for (int c = 0; c < CH; ++c) acc = dot4(bt.v[r][c], q[c], acc);
             acc = group_sum<G>(acc);
-            bool ok = row[r] < n_rows;
-            if constexpr (FILTER) ok = ok && source_ok(lds_allow, sid[r]);
+            bool ok = row < n_rows;
+            if constexpr (FILTER) ok = ok && source_ok(lds_allow, bt.sid[r]);
             if constexpr (SCORES) {
-                if (leader && row[r] < n_rows) scores_out[row[r]] = ok ? acc : neg_inf<float>();
+                if (leader && row < n_rows) scores_out[row] = ok ? acc : neg_inf<float>();
             } else {
-                const uint32_t r32 = (uint32_t)row[r];
+                const uint32_t r32 = (uint32_t)row;
                 top.offer_lanes(leader && ok && top.admits(acc, r32), acc, r32);
             }
         }
+    };
+    const int64_t step = (int64_t)gridDim.x * WAVES * RW;
+    int64_t base = ((int64_t)blockIdx.x * WAVES + wave) * RW;
+    Batch b0, b1;
+    if (base < n_rows) issue(base, b0);
+    while (base < n_rows) {
+        int64_t next = base + step;
+        if (next < n_rows) issue(next, b1);
+        reduce(base, b0);
+        base = next;
+        if (base >= n_rows) break;
+        next = base + step;
+        if (next < n_rows) issue(next, b0);
+        reduce(base, b1);
+        base = next;
     }
     if constexpr (!SCORES) {
         block_merge(top, lds_s, lds_r, WAVES);
@@ -176,7 +198,8 @@ int dense_scan_grid(const anrag_index *idx) {
 template <int G, int CH>
 static void launch_scan(int grid, hipStream_t st, const anrag_index *idx, const float *q, int32_t k,
                         const uint32_t *allow, float *scores_out, float *blk_s, uint32_t *blk_r) {
-    constexpr int R = (CH >= 8) ? 2 : 4;
+    // ~6 dwordx4 per lane per batch, two batches in flight (sweep at 768-d: R=2 7.05, R=3 6.96, R=4 6.86 TB/s)
+    constexpr int R = CH >= 6 ? 1 : (CH >= 3 ? 2 : (CH == 2 ? 3 : 6));
 #define ANRAG_SCAN(F, S)                                                                                     \
     dense_scan_kernel<G, CH, R, F, S><<<grid, kScanThreads, 0, st>>>(                                          \
         idx->d_emb, q, idx->n_rows, idx->dim, k, idx->d_dense_src, allow, blk_s, blk_r, scores_out)
