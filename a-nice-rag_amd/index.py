@@ -72,7 +72,8 @@ class Index:
     # ------------------------------------------------------------------ dense
     def dense_load(self, embeddings, source_id=None, doc_id=None, doc_id_base: int = 0) -> None:
         """Upload the row-major fp32 corpus matrix (numpy array, or an (address, n, d) tuple of a
-        device buffer such as a torch tensor's data_ptr())."""
+        device buffer such as a torch tensor's data_ptr()).  A device buffer must be COMPLETE when this is
+        called (synchronise the stream that produced it): the library copies on its own stream."""
         if isinstance(embeddings, tuple):
             addr, n, d = embeddings
             keep = None

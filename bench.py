@@ -95,6 +95,7 @@ def main():
     t_build = time.time()
     E = synth.dense_corpus(n_local, args.dim, 1234 + rank, device)
     idx = Index(local_rank)
+    torch.cuda.synchronize()  # device-pointer operands must be complete: the library copies on its own stream
     idx.dense_load((E.data_ptr(), n_local, args.dim), doc_id_base=lo)
     # queries: planted next to rows of rank 0's shard, identical on every rank
     Q, planted = synth.dense_queries(E, args.queries, 4321)
@@ -111,20 +112,26 @@ def main():
             dist.all_reduce(tot)
         avgdl = int(tot.item()) / args.rows
         idf = synth.bm25_idf(df.cpu().numpy(), args.rows)
+        torch.cuda.synchronize()
         idx.bm25_load(post["indptr"], (post["post_doc"].data_ptr(), post["post_doc"].numel()),
                       (post["post_tf"].data_ptr(), post["post_tf"].numel()), idf, post["doc_len"], avgdl,
                       synth.BM25_K1, synth.BM25_B, doc_id_base=lo)
-        term_lists = synth.bm25_queries(post, args.queries, 99) if rank == 0 else None
-        if world > 1:
-            box = [term_lists]
-            dist.broadcast_object_list(box, 0)
-            term_lists = box[0]
-    max_terms = max(1, max(len(t) for t in term_lists))
-    T = torch.full((args.queries, max_terms), -1, dtype=torch.int32, device=device)
-    for i, t in enumerate(term_lists):
-        if len(t):
-            T[i, : len(t)] = torch.from_numpy(np.asarray(t, dtype=np.int32)).to(device)
-    n_terms = [int(len(t)) for t in term_lists]
+        term_lists = synth.bm25_queries(post, args.queries, 99) if rank == 0 else []
+    # query term ids as one padded device tensor; rank 0's are broadcast so that every rank asks the same query
+    MAX_TERMS = 16
+    T = torch.full((args.queries, MAX_TERMS), -1, dtype=torch.int32, device=device)
+    NT = torch.zeros(args.queries, dtype=torch.int32, device=device)
+    if rank == 0:
+        for i, t in enumerate(term_lists):
+            t = np.asarray(t, dtype=np.int32)[:MAX_TERMS]
+            if len(t):
+                T[i, : len(t)] = torch.from_numpy(t).to(device)
+            NT[i] = len(t)
+    if world > 1:
+        dist.broadcast(T, 0)
+        dist.broadcast(NT, 0)
+    n_terms = [int(x) for x in NT.cpu().tolist()]
+    term_lists = [T[i, : n_terms[i]].cpu().numpy() for i in range(args.queries)]
     torch.cuda.synchronize()
     build_s = time.time() - t_build
 

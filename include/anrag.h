@@ -103,7 +103,9 @@ int anrag_index_sync(anrag_index *idx);
  * The upload point that replaces per-row np.frombuffer + DataFrame
  * (database_manager.py:39-66) and the per-query np.stack (search_engine.py:80):
  * `embeddings` is the row-major n_rows x dim fp32 matrix (host or device
- * pointer), copied once into HBM.
+ * pointer), copied once into HBM.  A device operand must be complete when the
+ * call is made (synchronise the stream that produced it): the copy runs on the
+ * index's own stream and the call returns when it has finished.
  *   source_id  nullable, n_rows x uint16: interned `source` string of each row
  *              (the column the filter of search_engine.py:36-55 looks at)
  *   doc_id     nullable, n_rows x int64: global doc id of each row; NULL means

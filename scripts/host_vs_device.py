@@ -8,9 +8,11 @@ from anrag.index import Index
 rows = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
 dev = torch.device("cuda", 0)
 E = synth.dense_corpus(rows, 768, 1234, dev)
+torch.cuda.synchronize()
 idx = Index(0); idx.dense_load((E.data_ptr(), rows, 768))
 post = synth.bm25_postings(rows, 200_000, 777, dev)
 idf = synth.bm25_idf(post["df"].cpu().numpy(), rows)
+torch.cuda.synchronize()
 idx.bm25_load(post["indptr"], (post["post_doc"].data_ptr(), post["post_doc"].numel()),
               (post["post_tf"].data_ptr(), post["post_tf"].numel()), idf, post["doc_len"], post["total_len"] / rows, 1.7, 0.83)
 Q, _ = synth.dense_queries(E, 64, 4321)

@@ -10,9 +10,11 @@ from anrag.index import Index
 rows, dim = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000, 768
 dev = torch.device("cuda", 0)
 E = synth.dense_corpus(rows, dim, 1234, dev)
+torch.cuda.synchronize()
 idx = Index(0); idx.dense_load((E.data_ptr(), rows, dim))
 post = synth.bm25_postings(rows, 200_000, 777, dev)
 idf = synth.bm25_idf(post["df"].cpu().numpy(), rows)
+torch.cuda.synchronize()
 idx.bm25_load(post["indptr"], (post["post_doc"].data_ptr(), post["post_doc"].numel()),
               (post["post_tf"].data_ptr(), post["post_tf"].numel()), idf, post["doc_len"], post["total_len"] / rows, 1.7, 0.83)
 Q, _ = synth.dense_queries(E, 64, 4321); Qh = Q.cpu().numpy()

@@ -13,6 +13,7 @@ k = int(sys.argv[4]) if len(sys.argv) > 4 else 10
 dev = torch.device("cuda", 0)
 E = synth.dense_corpus(n, d, 1234, dev)
 Q, rows = synth.dense_queries(E, nq, 4321)
+torch.cuda.synchronize()
 idx = Index(0); idx.dense_load((E.data_ptr(), n, d))
 lib = nat.load_library()
 out = torch.zeros((nq, k, 2), dtype=torch.int64, device=dev)

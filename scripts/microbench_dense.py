@@ -21,6 +21,7 @@ Q = E[:64] + 0.05 * torch.randn((64, d), device=dev, generator=g)
 Q /= Q.norm(dim=1, keepdim=True)
 torch.cuda.synchronize()
 idx = Index(0)
+torch.cuda.synchronize()
 idx.dense_load((E.data_ptr(), n, d))
 out = torch.empty((64 * k, 2), device=dev, dtype=torch.float64)
 # correctness spot check against torch

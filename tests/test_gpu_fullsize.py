@@ -26,10 +26,12 @@ def world():
     E = synth.dense_corpus(N, D, 1234, dev)
     Q, planted = synth.dense_queries(E, 32, 4321)
     idx = Index(0)
+    torch.cuda.synchronize()  # device-pointer operands must be complete before the library copies them
     idx.dense_load((E.data_ptr(), N, D))
     post = synth.bm25_postings(N, 200_000, 777, dev)
     idf = synth.bm25_idf(post["df"].cpu().numpy(), N)
     avgdl = post["total_len"] / N
+    torch.cuda.synchronize()
     idx.bm25_load(post["indptr"], (post["post_doc"].data_ptr(), post["post_doc"].numel()),
                   (post["post_tf"].data_ptr(), post["post_tf"].numel()), idf, post["doc_len"], avgdl, 1.7, 0.83)
     yield dict(torch=torch, E=E, Q=Q, planted=planted, idx=idx, post=post, idf=idf, avgdl=avgdl)
