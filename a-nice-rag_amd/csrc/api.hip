@@ -94,7 +94,6 @@ static int ensure_common_workspace(anrag_index *idx) {
     if (!idx->d_cand_a) {
         idx->cand_cap = 4096;  // records per buffer (n_queries * k per call is chunked to this)
         if ((rc = dev_alloc(idx, &idx->d_cand_a, idx->cand_cap))) return rc;
-        if ((rc = dev_alloc(idx, &idx->d_cand_b, idx->cand_cap))) return rc;
         if ((rc = dev_alloc(idx, &idx->d_cand_out, idx->cand_cap))) return rc;
     }
     if (!idx->h_pinned) {
@@ -198,8 +197,6 @@ int anrag_index_create(int device, anrag_index **out) {
     hipError_t e = hipStreamCreateWithFlags(&idx->own_primary, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&idx->own_secondary, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&idx->own_fusion, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&idx->ev_fork, hipEventDisableTiming);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&idx->ev_join, hipEventDisableTiming);
     for (int b = 0; b < 2 && e == hipSuccess; ++b) {
         e = hipEventCreateWithFlags(&idx->ev_scan[b], hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&idx->ev_bm25[b], hipEventDisableTiming);
@@ -238,7 +235,7 @@ int anrag_index_destroy(anrag_index *idx) {
         free_dense(idx);
         free_bm25(idx);
         void *ptrs[] = {idx->d_blk_score_f32, idx->d_blk_row_a, idx->d_blk_score_f64, idx->d_blk_row_b, idx->d_query,
-                        idx->d_allow_a,       idx->d_allow_b,   idx->d_terms,         idx->d_cand_a,    idx->d_cand_b,
+                        idx->d_allow_a,       idx->d_allow_b,   idx->d_terms,         idx->d_cand_a,
                         idx->d_cand_out,      idx->d_scores_f64, idx->d_sort_tmp,     idx->d_sort_buf};
         for (void *p : ptrs)
             if (p) (void)hipFree(p);
@@ -246,8 +243,6 @@ int anrag_index_destroy(anrag_index *idx) {
         free_batched(idx);
         if (idx->h_pinned) (void)hipHostFree(idx->h_pinned);
         for (hipEvent_t e : idx->event_pool) (void)hipEventDestroy(e);
-        if (idx->ev_fork) (void)hipEventDestroy(idx->ev_fork);
-        if (idx->ev_join) (void)hipEventDestroy(idx->ev_join);
         for (int b = 0; b < 2; ++b) {
             hipEvent_t evs[] = {idx->ev_scan[b], idx->ev_bm25[b], idx->ev_fused[b]};
             for (hipEvent_t ev : evs)

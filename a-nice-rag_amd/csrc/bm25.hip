@@ -334,7 +334,6 @@ int bm25_load(anrag_index *idx, const int64_t *indptr, int64_t n_terms, const in
     idx->d_blk_row_b = nullptr;
     ANRAG_HIP(hipMalloc(reinterpret_cast<void **>(&idx->d_blk_score_f64), (size_t)idx->n_parts * kListLen * 8));
     ANRAG_HIP(hipMalloc(reinterpret_cast<void **>(&idx->d_blk_row_b), (size_t)idx->n_parts * kListLen * 4));
-    idx->blk_lists_b = idx->n_parts;
     return ANRAG_OK;
 }
 

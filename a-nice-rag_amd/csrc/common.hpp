@@ -56,7 +56,6 @@ struct anrag_index {
     // sharded path, the caller's collectives).  A hybrid query touches all three and never syncs the host.
     hipStream_t own_primary = nullptr, own_secondary = nullptr, own_fusion = nullptr;
     hipStream_t primary = nullptr, secondary = nullptr, fusion = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // hybrid pipeline, double-buffered on (query sequence number & 1)
     hipEvent_t ev_scan[2] = {nullptr, nullptr};    // scan of buffer b finished (primary)
     hipEvent_t ev_bm25[2] = {nullptr, nullptr};    // BM25 candidates of buffer b ready (secondary)
@@ -91,12 +90,11 @@ struct anrag_index {
     uint32_t *d_blk_row_a = nullptr;
     double *d_blk_score_f64 = nullptr;  // BM25 per-partition lists
     uint32_t *d_blk_row_b = nullptr;
-    int32_t blk_lists_b = 0;
     float *d_query = nullptr;           // staged queries
     int64_t query_cap = 0;
     uint32_t *d_allow_a = nullptr, *d_allow_b = nullptr;  // staged allow bitmaps (2048 words each)
     int32_t *d_terms = nullptr;         // staged term ids
-    anrag_candidate *d_cand_a = nullptr, *d_cand_b = nullptr, *d_cand_out = nullptr;
+    anrag_candidate *d_cand_a = nullptr, *d_cand_out = nullptr;
     int64_t cand_cap = 0;
     void *h_pinned = nullptr;           // result staging
     int64_t pinned_bytes = 0;

@@ -16,12 +16,12 @@
 //   3. SELECT        a wave per query ranks its survivors (score desc, row asc) -> k records.
 //   A query whose list overflows its capacity is flagged (count = -1) and redone by K1.
 //
-// Tiling (wave64, 8 waves = 512 threads, 2 waves per SIMD so one wave's LDS/barrier waits hide under the
-// other's MFMAs): workgroup tile = 128 corpus rows x 256 queries, BK = 32; corpus rows are the MFMA A
-// operand (rows of D), queries the B operand (columns of D), so a LANE owns one query column and its
-// threshold.  Wave w: rows (w&1)*64.., queries (w>>1)*64.. -> 2x2 tiles of 32x32 = 64 accumulators.
-// LDS images [row][32 k + 4 pad] fp32 (pad breaks the 128-B row stride for ds_read_b128), double
-// buffered (110 KB); global -> registers -> LDS staging issued one k-step ahead.  Each lane reads FOUR
+// Tiling (wave64): workgroup tile = 128 corpus rows x QW queries, BK = 32, 2 waves per SIMD on the CU either as
+// one 8-wave workgroup (QW = 256) or as two 4-wave workgroups (QW = 128) -- BatchGeom below.  Corpus rows are the
+// MFMA A operand (rows of D), queries the B operand (columns of D), so a LANE owns one query column and its
+// threshold.  Wave w: rows (w&1)*64.., queries (w>>1)*64.. -> 2x2 tiles of 32x32 = 64 accumulators.  LDS images
+// [row][32 k + 4 pad] fp32 (pad breaks the 128-B row stride for ds_read_b128), double buffered (110 / 74 KB per
+// workgroup); global -> registers -> LDS staging two k-steps ahead.  Each lane reads FOUR
 // consecutive k per ds_read_b128 and feeds them to four MFMAs: MFMA s of group g sums k = 8g+s (lane
 // half 0) and k = 8g+4+s (lane half 1) -- a permutation of k, identical on the A and B side.
 #include "common.hpp"
@@ -36,52 +36,67 @@ constexpr int kBM = 128;         // corpus rows per workgroup tile
 constexpr int kBQ = 256;         // queries per pass
 constexpr int kBK = 32;          // k per staging step
 constexpr int kLdk = kBK + 4;    // padded LDS row (floats)
-constexpr int kBatchThreads = 512;
-constexpr int kBufFloats = (kBM + kBQ) * kLdk;
-constexpr int kBatchLdsBytes = 2 * kBufFloats * 4;
+// QW = queries per workgroup.  256: one 8-wave workgroup per CU (2 waves per SIMD), the whole pass against each
+// corpus tile -- fewest staged bytes per MFMA, best for full passes.  128: 4-wave workgroups, two per CU; a pass of
+// <= 128 queries does half the matrix work instead of multiplying zero padding (measured, 1M x 768: 256 queries
+// 3.52 ms with QW=256 vs 3.65 ms with 2 x QW=128; 128 queries 2.02 ms with QW=128).
+template <int QW>
+struct BatchGeom {
+    static constexpr int kThreads = QW * 2;                 // waves = 2 (row halves) x QW/64 (query columns)
+    static constexpr int kBufFloats = (kBM + QW) * kLdk;
+    static constexpr int kLdsBytes = 2 * kBufFloats * 4;
+    static constexpr int kStageE = kBM * 8 / kThreads;      // float4 per thread per k-step, corpus tile
+    static constexpr int kStageQ = QW * 8 / kThreads;       // = 4
+};
 
 struct Cand32 {
     float score;
     uint32_t row;
 };
 
-template <bool SAMPLE, bool FILTER>
-__global__ __launch_bounds__(kBatchThreads, 2) void dense_batched_kernel(
-    const float *__restrict__ emb, const float *__restrict__ queries /* [kBQ][dim], zero padded */,
+template <int QW, bool SAMPLE, bool FILTER>
+__global__ __launch_bounds__(BatchGeom<QW>::kThreads, 2) void dense_batched_kernel(
+    const float *__restrict__ emb, const float *__restrict__ queries /* [kBQ][dim], zero padded */, int32_t n_qblocks,
     int64_t n_rows /* corpus rows */, int32_t dim, int32_t nq, int64_t n_work /* rows this pass visits */,
     int64_t stride /* SAMPLE: corpus row = work row * stride */, const float *__restrict__ tau,
     float *__restrict__ sample_scores /* [kBQ][n_work] */, int32_t *__restrict__ cnt, Cand32 *__restrict__ cand,
     int32_t cap, const uint16_t *__restrict__ src, const uint32_t *__restrict__ allow_bits) {
+    using Geo = BatchGeom<QW>;
+    constexpr int kBatchThreads = Geo::kThreads, kBufFloats = Geo::kBufFloats, kBQW = QW;
+    constexpr int NE = Geo::kStageE, NQ = Geo::kStageQ;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    __shared__ __attribute__((aligned(16))) uint32_t lds_allow[FILTER ? 2048 : 4];  // 16-B multiple: keeps the dynamic base aligned
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lh = lane >> 5;
     const int rw = wave & 1, qw = wave >> 1;
-    if constexpr (FILTER) {
-        for (int i = tid; i < 2048; i += kBatchThreads) lds_allow[i] = allow_bits[i];
-    }
+    // the source filter is consulted for survivors only (rare), straight from the L2-resident bitmap: keeping it
+    // in LDS would push two workgroups past the CU's 160 KB
     const int ksteps = dim / kBK;
     const int64_t n_tiles = (n_work + kBM - 1) / kBM;
-    const int64_t my_tiles = blockIdx.x < n_tiles ? (n_tiles - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
+    // workgroup -> (query block, first corpus tile); tiles are strided by the workgroups of the same query block
+    const int qblock = blockIdx.x % n_qblocks;
+    const int64_t first_tile = blockIdx.x / n_qblocks;
+    const int64_t tile_step = gridDim.x / n_qblocks;
+    const int qbase = qblock * kBQW;
+    const int64_t my_tiles = first_tile < n_tiles ? (n_tiles - first_tile + tile_step - 1) / tile_step : 0;
     const int64_t total = my_tiles * ksteps;
 
     // this lane's thresholds: query columns qw*64 + tj*32 + l31
     float my_tau[2] = {0.f, 0.f};
     if constexpr (!SAMPLE) {
 #pragma unroll
-        for (int tj = 0; tj < 2; ++tj) my_tau[tj] = tau[qw * 64 + tj * 32 + l31];
+        for (int tj = 0; tj < 2; ++tj) my_tau[tj] = tau[qbase + qw * 64 + tj * 32 + l31];
     }
 
     // Staging cursor: (tile, k-step) of the NEXT load_stage call, advanced incrementally -- a 64-bit divide and
     // six 64-bit address multiplies per k-step were ~10 % of the loop before.
-    f32x4 stage_e[2], stage_q[4];
-    int64_t ld_tile = blockIdx.x;
+    f32x4 stage_e[NE], stage_q[NQ];
+    int64_t ld_tile = first_tile;
     int ld_ks = 0;
-    const float *pe[2];
-    const float *pq[4];
+    const float *pe[NE];
+    const float *pq[NQ];
     auto point_rows = [&]() {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < NE; ++i) {
             const int f = tid + i * kBatchThreads;
             int64_t wr = ld_tile * kBM + (f >> 3);
             if (wr >= n_work) wr = n_work - 1;
@@ -90,19 +105,19 @@ __global__ __launch_bounds__(kBatchThreads, 2) void dense_batched_kernel(
         }
     };
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NQ; ++i) {
         const int f = tid + i * kBatchThreads;
-        pq[i] = queries + (int64_t)(f >> 3) * dim + (f & 7) * 4;
+        pq[i] = queries + (int64_t)(qbase + (f >> 3)) * dim + (f & 7) * 4;
     }
     point_rows();
     auto load_stage = [&]() {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) stage_e[i] = *reinterpret_cast<const f32x4 *>(pe[i] + ld_ks * kBK);
+        for (int i = 0; i < NE; ++i) stage_e[i] = *reinterpret_cast<const f32x4 *>(pe[i] + ld_ks * kBK);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) stage_q[i] = *reinterpret_cast<const f32x4 *>(pq[i] + ld_ks * kBK);
+        for (int i = 0; i < NQ; ++i) stage_q[i] = *reinterpret_cast<const f32x4 *>(pq[i] + ld_ks * kBK);
         if (++ld_ks == ksteps) {
             ld_ks = 0;
-            ld_tile += gridDim.x;
+            ld_tile += tile_step;
             point_rows();
         }
     };
@@ -110,12 +125,12 @@ __global__ __launch_bounds__(kBatchThreads, 2) void dense_batched_kernel(
         float *es = lds + buf * kBufFloats;
         float *qs = es + kBM * kLdk;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < NE; ++i) {
             const int f = tid + i * kBatchThreads;
             *reinterpret_cast<f32x4 *>(es + (f >> 3) * kLdk + (f & 7) * 4) = stage_e[i];
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NQ; ++i) {
             const int f = tid + i * kBatchThreads;
             *reinterpret_cast<f32x4 *>(qs + (f >> 3) * kLdk + (f & 7) * 4) = stage_q[i];
         }
@@ -139,7 +154,7 @@ __global__ __launch_bounds__(kBatchThreads, 2) void dense_batched_kernel(
         if (total > 1) load_stage();
     }
     __syncthreads();
-    int64_t cur_tile = blockIdx.x;
+    int64_t cur_tile = first_tile;
     int cur_ks = 0;
     for (int64_t it = 0; it < total; ++it) {
         const int buf = (int)(it & 1);
@@ -147,32 +162,43 @@ __global__ __launch_bounds__(kBatchThreads, 2) void dense_batched_kernel(
         if (it + 2 < total) load_stage();
         const float *es = lds + buf * kBufFloats + (rw * 64 + l31) * kLdk + lh * 4;
         const float *qs = lds + buf * kBufFloats + kBM * kLdk + (qw * 64 + l31) * kLdk + lh * 4;
+        // operand fragments of k-group g+1 are read from LDS while the 16 MFMAs of group g issue (separate
+        // registers: no write-after-read wait on the fragments the matrix pipe is still consuming)
+        f32x4 fa[2][2], fb[2][2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            fa[0][t] = *reinterpret_cast<const f32x4 *>(es + t * 32 * kLdk);
+            fb[0][t] = *reinterpret_cast<const f32x4 *>(qs + t * 32 * kLdk);
+        }
 #pragma unroll
         for (int g = 0; g < kBK / 8; ++g) {
-            f32x4 a[2], b[2];
+            const int cur = g & 1, nxt = cur ^ 1;
+            if (g + 1 < kBK / 8) {
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                a[t] = *reinterpret_cast<const f32x4 *>(es + t * 32 * kLdk + g * 8);
-                b[t] = *reinterpret_cast<const f32x4 *>(qs + t * 32 * kLdk + g * 8);
+                for (int t = 0; t < 2; ++t) {
+                    fa[nxt][t] = *reinterpret_cast<const f32x4 *>(es + t * 32 * kLdk + (g + 1) * 8);
+                    fb[nxt][t] = *reinterpret_cast<const f32x4 *>(qs + t * 32 * kLdk + (g + 1) * 8);
+                }
             }
+            __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of this group's MFMAs
 #pragma unroll
             for (int s = 0; s < 4; ++s)
 #pragma unroll
                 for (int ti = 0; ti < 2; ++ti)
 #pragma unroll
                     for (int tj = 0; tj < 2; ++tj)
-                        acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ti][s], b[tj][s], acc[ti][tj], 0, 0, 0);
+                        acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][ti][s], fb[cur][tj][s], acc[ti][tj], 0, 0, 0);
         }
         if (++cur_ks == ksteps) {
             // ---- epilogue of one 128 x 256 tile: D[row][query], lane = query column, 16 rows per register set
             const int64_t tile = cur_tile;
             cur_ks = 0;
-            cur_tile += gridDim.x;
+            cur_tile += tile_step;
 #pragma unroll
             for (int ti = 0; ti < 2; ++ti)
 #pragma unroll
                 for (int tj = 0; tj < 2; ++tj) {
-                    const int q = qw * 64 + tj * 32 + l31;
+                    const int q = qbase + qw * 64 + tj * 32 + l31;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int64_t wr = tile * kBM + rw * 64 + ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
@@ -180,13 +206,13 @@ __global__ __launch_bounds__(kBatchThreads, 2) void dense_batched_kernel(
                         if constexpr (SAMPLE) {
                             if (wr < n_work) {
                                 bool ok = true;
-                                if constexpr (FILTER) ok = source_ok(lds_allow, src[wr * stride]);
+                                if constexpr (FILTER) ok = source_ok(allow_bits, src[wr * stride]);
                                 sample_scores[(int64_t)q * n_work + wr] = ok ? s : neg_inf<float>();
                             }
                         } else {
                             if (s >= my_tau[tj] && wr < n_work && q < nq) {
                                 bool ok = true;
-                                if constexpr (FILTER) ok = source_ok(lds_allow, src[wr]);
+                                if constexpr (FILTER) ok = source_ok(allow_bits, src[wr]);
                                 if (ok) {
                                     const int pos = atomicAdd(&cnt[q], 1);
                                     if (pos < cap) {
@@ -292,6 +318,52 @@ void free_batched(anrag_index *idx) {
     idx->bsample_cap = 0;
 }
 
+template <int QW>
+static int batched_passes(anrag_index *idx, hipStream_t st, int32_t nq, int32_t k, int64_t n_sample, int64_t stride,
+                          const uint32_t *allow, Cand32 *cand) {
+    using Geo = BatchGeom<QW>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        ANRAG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&dense_batched_kernel<QW, true, false>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, Geo::kLdsBytes));
+        ANRAG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&dense_batched_kernel<QW, true, true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, Geo::kLdsBytes));
+        ANRAG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&dense_batched_kernel<QW, false, false>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, Geo::kLdsBytes));
+        ANRAG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&dense_batched_kernel<QW, false, true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, Geo::kLdsBytes));
+        attr_set = true;
+    }
+    const int64_t n = idx->n_rows;
+    const int dim = idx->dim;
+    const int n_qblocks = (nq + QW - 1) / QW;  // 1
+    const int wg_per_cu = 512 / Geo::kThreads;  // 8 waves per CU either way
+    auto grid_for = [&](int64_t rows) {
+        const int64_t tiles = (rows + kBM - 1) / kBM;
+        const int64_t per_block = (int64_t)wg_per_cu * idx->n_cus / n_qblocks;
+        return (unsigned)((tiles < per_block ? tiles : per_block) * n_qblocks);
+    };
+    if (allow)
+        dense_batched_kernel<QW, true, true><<<grid_for(n_sample), Geo::kThreads, Geo::kLdsBytes, st>>>(
+            idx->d_emb, idx->d_bq, n_qblocks, n, dim, nq, n_sample, stride, nullptr, idx->d_bsample, nullptr, nullptr, 0,
+            idx->d_dense_src, allow);
+    else
+        dense_batched_kernel<QW, true, false><<<grid_for(n_sample), Geo::kThreads, Geo::kLdsBytes, st>>>(
+            idx->d_emb, idx->d_bq, n_qblocks, n, dim, nq, n_sample, stride, nullptr, idx->d_bsample, nullptr, nullptr, 0,
+            nullptr, nullptr);
+    batched_threshold_kernel<<<kBQ, 64, 0, st>>>(idx->d_bsample, n_sample, k, idx->d_btau, idx->d_bcnt);
+    if (allow)
+        dense_batched_kernel<QW, false, true><<<grid_for(n), Geo::kThreads, Geo::kLdsBytes, st>>>(
+            idx->d_emb, idx->d_bq, n_qblocks, n, dim, nq, n, 1, idx->d_btau, nullptr, idx->d_bcnt, cand, kCandCap,
+            idx->d_dense_src, allow);
+    else
+        dense_batched_kernel<QW, false, false><<<grid_for(n), Geo::kThreads, Geo::kLdsBytes, st>>>(
+            idx->d_emb, idx->d_bq, n_qblocks, n, dim, nq, n, 1, idx->d_btau, nullptr, idx->d_bcnt, cand, kCandCap, nullptr,
+            nullptr);
+    ANRAG_HIP(hipGetLastError());
+    return ANRAG_OK;
+}
+
 // One pass of up to 256 queries (device pointers); d_out: nq x k records, d_flag: nq ints (0 ok, -1 redo).
 int launch_dense_batched(anrag_index *idx, hipStream_t st, const float *d_queries, int32_t nq, int32_t k,
                          const uint32_t *d_allow_bits, anrag_candidate *d_out, int32_t *d_flag) {
@@ -306,45 +378,15 @@ int launch_dense_batched(anrag_index *idx, hipStream_t st, const float *d_querie
     const int64_t stride = n / n_sample;
     int rc = ensure_batched_workspace(idx, n_sample);
     if (rc) return rc;
-    static bool attr_set = false;
-    if (!attr_set) {
-        ANRAG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&dense_batched_kernel<true, false>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, kBatchLdsBytes));
-        ANRAG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&dense_batched_kernel<true, true>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, kBatchLdsBytes));
-        ANRAG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&dense_batched_kernel<false, false>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, kBatchLdsBytes));
-        ANRAG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&dense_batched_kernel<false, true>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, kBatchLdsBytes));
-        attr_set = true;
-    }
     // zero-padded query block
     ANRAG_HIP(hipMemsetAsync(idx->d_bq, 0, (size_t)kBQ * dim * sizeof(float), st));
     ANRAG_HIP(hipMemcpyAsync(idx->d_bq, d_queries, (size_t)nq * dim * sizeof(float), hipMemcpyDeviceToDevice, st));
-    auto grid_for = [&](int64_t rows) {
-        const int64_t tiles = (rows + kBM - 1) / kBM;
-        return (unsigned)(tiles < idx->n_cus ? tiles : idx->n_cus);
-    };
+    Cand32 *cand = reinterpret_cast<Cand32 *>(idx->d_bcand);
     {
         LaunchTimer t(idx, ANRAG_KERNEL_DENSE_BATCHED, st);
-        if (allow)
-            dense_batched_kernel<true, true><<<grid_for(n_sample), kBatchThreads, kBatchLdsBytes, st>>>(
-                idx->d_emb, idx->d_bq, n, dim, nq, n_sample, stride, nullptr, idx->d_bsample, nullptr, nullptr, 0,
-                idx->d_dense_src, allow);
-        else
-            dense_batched_kernel<true, false><<<grid_for(n_sample), kBatchThreads, kBatchLdsBytes, st>>>(
-                idx->d_emb, idx->d_bq, n, dim, nq, n_sample, stride, nullptr, idx->d_bsample, nullptr, nullptr, 0,
-                nullptr, nullptr);
-        batched_threshold_kernel<<<kBQ, 64, 0, st>>>(idx->d_bsample, n_sample, k, idx->d_btau, idx->d_bcnt);
-        if (allow)
-            dense_batched_kernel<false, true><<<grid_for(n), kBatchThreads, kBatchLdsBytes, st>>>(
-                idx->d_emb, idx->d_bq, n, dim, nq, n, 1, idx->d_btau, nullptr, idx->d_bcnt,
-                reinterpret_cast<Cand32 *>(idx->d_bcand), kCandCap, idx->d_dense_src, allow);
-        else
-            dense_batched_kernel<false, false><<<grid_for(n), kBatchThreads, kBatchLdsBytes, st>>>(
-                idx->d_emb, idx->d_bq, n, dim, nq, n, 1, idx->d_btau, nullptr, idx->d_bcnt,
-                reinterpret_cast<Cand32 *>(idx->d_bcand), kCandCap, nullptr, nullptr);
-        ANRAG_HIP(hipGetLastError());
+        int rc2 = nq > 128 ? batched_passes<256>(idx, st, nq, k, n_sample, stride, allow, cand)
+                           : batched_passes<128>(idx, st, nq, k, n_sample, stride, allow, cand);
+        if (rc2) return rc2;
     }
     {
         LaunchTimer t(idx, ANRAG_KERNEL_SELECT, st);
