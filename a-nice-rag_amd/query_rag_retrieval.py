@@ -113,12 +113,18 @@ class RetrievalEvaluationSystem:
             want_bm25 = use_hybrid_search and bm25 is not None and model_weights.get("BM25", 0) > 0
             will_rerank = use_reranker and bool(query_text)
 
-            # ---- fused single-call route: one dense model + BM25 tokens, ids out, no rerank
+            # ---- fused single-call route: one dense model + BM25, ids out, no rerank.  Tokens as the reference
+            # picks them: pre-tokenised if given (:307), else the query text through the tokeniser (:317, use_lemmatized)
+            fused_tokens = query_tokens
+            if not fused_tokens and query_text and want_bm25:
+                from .preprocess_bm25 import preprocess_text
+
+                fused_tokens = preprocess_text(query_text, use_lemmatization=True)
             if (self.fused and not return_docs and not will_rerank and len(active) == 1 and want_bm25
-                    and query_tokens and similarity_k <= 64):
+                    and fused_tokens and similarity_k <= 64):
                 key, df = active[0]
                 ids = self.search_engine.hybrid_search_ids(
-                    query_embeddings[key], df, model_weights.get(key, 1.0), query_tokens, bm25, bm25_sections,
+                    query_embeddings[key], df, model_weights.get(key, 1.0), fused_tokens, bm25, bm25_sections,
                     bm25_section_ids, model_weights.get("BM25", 1.0), similarity_k, common_sections_n, wrrf_k,
                     filename_type_filter)
                 if ids is not None:
