@@ -51,6 +51,7 @@ _SIGNATURES = {
     "anrag_dense_search": [_p, _p, _i32, _i32, _p, _i32, _p, _p, _p],
     "anrag_dense_search_device": [_p, _p, _i32, _i32, _p, _p],
     "anrag_dense_search_batch_device": [_p, _p, _i32, _i32, _p, _p, _p],
+    "anrag_set_batched_precision": [_p, _i32],
     "anrag_dense_scores": [_p, _p, _p],
     "anrag_bm25_load": [_p, _p, _i64, _p, _p, _p, _p, _i64, _f64, _f64, _f64, _p, _p, _i64],
     "anrag_bm25_search": [_p, _p, _i32, _i32, _p, _i32, _p, _p, _p],

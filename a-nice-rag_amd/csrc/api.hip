@@ -427,6 +427,13 @@ int anrag_dense_search_batch_device(anrag_index *idx, const float *d_queries, in
     return launch_dense_batched(idx, idx->primary, d_queries, n_queries, k, d_allow_bits, d_out, d_flag);
 }
 
+int anrag_set_batched_precision(anrag_index *idx, int32_t mode) {
+    ANRAG_ENTER(idx);
+    ANRAG_REQUIRE(mode == 0 || mode == 1, "mode must be 0 (exact f32 MFMA) or 1 (bf16 x 3 split products)");
+    idx->batched_split = mode == 1;
+    return ANRAG_OK;
+}
+
 int anrag_dense_search(anrag_index *idx, const float *queries, int32_t n_queries, int32_t k,
                        const uint8_t *allow_source, int32_t n_sources, int64_t *out_doc, float *out_score,
                        int32_t *out_count) {

@@ -109,6 +109,8 @@ struct anrag_index {
     int32_t *d_bcnt = nullptr, *d_bflag = nullptr;
     void *d_bcand = nullptr;
     int64_t bsample_cap = 0;
+    bool batched_split = false;         // K2 arithmetic: false = exact f32 MFMA, true = bf16 x 3 split products
+    void *d_bq_hi = nullptr, *d_bq_lo = nullptr;  // bf16 halves of the padded query block
     // WRRF scratch
     int64_t *d_w_ids = nullptr, *d_w_in = nullptr;
     double *d_w_contrib = nullptr, *d_w_score = nullptr;

@@ -24,17 +24,10 @@
 // workgroup); global -> registers -> LDS staging two k-steps ahead.  Each lane reads FOUR
 // consecutive k per ds_read_b128 and feeds them to four MFMAs: MFMA s of group g sums k = 8g+s (lane
 // half 0) and k = 8g+4+s (lane half 1) -- a permutation of k, identical on the A and B side.
-#include "common.hpp"
-#include "wave_topk.hpp"
+#include "dense_batched_common.hpp"
 
 namespace anrag {
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-constexpr int kBM = 128;         // corpus rows per workgroup tile
-constexpr int kBQ = 256;         // queries per pass
-constexpr int kBK = 32;          // k per staging step
 constexpr int kLdk = kBK + 4;    // padded LDS row (floats)
 // QW = queries per workgroup.  256: one 8-wave workgroup per CU (2 waves per SIMD), the whole pass against each
 // corpus tile -- fewest staged bytes per MFMA, best for full passes.  128: 4-wave workgroups, two per CU; a pass of
@@ -47,11 +40,6 @@ struct BatchGeom {
     static constexpr int kLdsBytes = 2 * kBufFloats * 4;
     static constexpr int kStageE = kBM * 8 / kThreads;      // float4 per thread per k-step, corpus tile
     static constexpr int kStageQ = QW * 8 / kThreads;       // = 4
-};
-
-struct Cand32 {
-    float score;
-    uint32_t row;
 };
 
 template <int QW, bool SAMPLE, bool FILTER>
@@ -190,43 +178,10 @@ __global__ __launch_bounds__(BatchGeom<QW>::kThreads, 2) void dense_batched_kern
                         acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][ti][s], fb[cur][tj][s], acc[ti][tj], 0, 0, 0);
         }
         if (++cur_ks == ksteps) {
-            // ---- epilogue of one 128 x 256 tile: D[row][query], lane = query column, 16 rows per register set
-            const int64_t tile = cur_tile;
+            batched_tile_epilogue<SAMPLE, FILTER>(acc, cur_tile, rw, qw, qbase, l31, lh, my_tau, n_work, stride, nq,
+                                                  sample_scores, cnt, cand, cap, src, allow_bits);
             cur_ks = 0;
             cur_tile += tile_step;
-#pragma unroll
-            for (int ti = 0; ti < 2; ++ti)
-#pragma unroll
-                for (int tj = 0; tj < 2; ++tj) {
-                    const int q = qbase + qw * 64 + tj * 32 + l31;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int64_t wr = tile * kBM + rw * 64 + ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                        const float s = acc[ti][tj][r];
-                        if constexpr (SAMPLE) {
-                            if (wr < n_work) {
-                                bool ok = true;
-                                if constexpr (FILTER) ok = source_ok(allow_bits, src[wr * stride]);
-                                sample_scores[(int64_t)q * n_work + wr] = ok ? s : neg_inf<float>();
-                            }
-                        } else {
-                            if (s >= my_tau[tj] && wr < n_work && q < nq) {
-                                bool ok = true;
-                                if constexpr (FILTER) ok = source_ok(allow_bits, src[wr]);
-                                if (ok) {
-                                    const int pos = atomicAdd(&cnt[q], 1);
-                                    if (pos < cap) {
-                                        Cand32 c;
-                                        c.score = s;
-                                        c.row = (uint32_t)wr;
-                                        cand[(int64_t)q * cap + pos] = c;
-                                    }
-                                }
-                            }
-                        }
-                        acc[ti][tj][r] = 0.f;
-                    }
-                }
         }
         __syncthreads();
     }
@@ -283,8 +238,6 @@ __global__ __launch_bounds__(64) void batched_select_kernel(const Cand32 *__rest
 }
 
 // ------------------------------------------------------------------ host side
-constexpr int32_t kCandCap = 8192;
-
 bool batched_path_applies(const anrag_index *idx, int32_t n_queries, int32_t k) {
     return n_queries >= 16 && k <= ANRAG_FUSED_K_MAX && idx->dim % kBK == 0 && idx->n_rows >= 65536;
 }
@@ -309,12 +262,13 @@ static int ensure_batched_workspace(anrag_index *idx, int64_t n_sample) {
 }
 
 void free_batched(anrag_index *idx) {
-    void *ptrs[] = {idx->d_bq, idx->d_btau, idx->d_bcnt, idx->d_bflag, idx->d_bcand, idx->d_bsample};
+    void *ptrs[] = {idx->d_bq,    idx->d_btau,    idx->d_bcnt,  idx->d_bflag,
+                    idx->d_bcand, idx->d_bsample, idx->d_bq_hi, idx->d_bq_lo};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     idx->d_bq = idx->d_btau = idx->d_bsample = nullptr;
     idx->d_bcnt = idx->d_bflag = nullptr;
-    idx->d_bcand = nullptr;
+    idx->d_bcand = idx->d_bq_hi = idx->d_bq_lo = nullptr;
     idx->bsample_cap = 0;
 }
 
@@ -384,8 +338,9 @@ int launch_dense_batched(anrag_index *idx, hipStream_t st, const float *d_querie
     Cand32 *cand = reinterpret_cast<Cand32 *>(idx->d_bcand);
     {
         LaunchTimer t(idx, ANRAG_KERNEL_DENSE_BATCHED, st);
-        int rc2 = nq > 128 ? batched_passes<256>(idx, st, nq, k, n_sample, stride, allow, cand)
-                           : batched_passes<128>(idx, st, nq, k, n_sample, stride, allow, cand);
+        int rc2 = idx->batched_split ? batched_passes_split(idx, st, nq, k, n_sample, stride, allow, cand)
+                  : nq > 128       ? batched_passes<256>(idx, st, nq, k, n_sample, stride, allow, cand)
+                                   : batched_passes<128>(idx, st, nq, k, n_sample, stride, allow, cand);
         if (rc2) return rc2;
     }
     {

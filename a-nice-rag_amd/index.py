@@ -106,6 +106,11 @@ class Index:
                                                doc.ctypes.data, score.ctypes.data, count.ctypes.data))
         return doc, score, count
 
+    def set_batched_precision(self, mode: str = "f32") -> None:
+        """"f32": exact f32 MFMA (default).  "bf16x3": split-precision products on the bf16 matrix cores (scores within
+        ~3e-5 of f32 for unit-norm vectors)."""
+        nat.check(self._lib.anrag_set_batched_precision(self.handle, {"f32": 0, "bf16x3": 1}[mode]))
+
     def dense_scores(self, query) -> np.ndarray:
         q = _f32(query).reshape(-1)
         assert q.size == self.dim

@@ -47,6 +47,8 @@ def parse_args():
     ap.add_argument("--workload", choices=["hybrid", "dense", "batched"], default="hybrid",
                     help="hybrid = headline (C3); dense = K1 only (C2-shaped); batched = 256-query MFMA passes (C4)")
     ap.add_argument("--batch", type=int, default=256, help="queries per pass of --workload batched")
+    ap.add_argument("--batch-precision", choices=["f32", "bf16x3"], default="f32",
+                    help="--workload batched: exact f32 MFMA (default) or opt-in split-precision bf16 x 3 products")
     ap.add_argument("--exchange-group", type=int, default=4,
                     help="N > 1: in-flight queries that share one all-gather (each is still scanned alone)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -97,6 +99,8 @@ def main():
     idx = Index(local_rank)
     torch.cuda.synchronize()  # device-pointer operands must be complete: the library copies on its own stream
     idx.dense_load((E.data_ptr(), n_local, args.dim), doc_id_base=lo)
+    if batched:
+        idx.set_batched_precision(args.batch_precision)
     # queries: planted next to rows of rank 0's shard, identical on every rank
     Q, planted = synth.dense_queries(E, args.queries, 4321)
     if world > 1:
@@ -251,13 +255,18 @@ def main():
         if batched:
             flop = 2.0 * args.batch * n_local * args.dim  # 2*Q*N*D per pass
             tf = flop / (scan_avg_ms * 1e-3) / 1e12 if scan_n else 0.0
+            split = args.batch_precision == "bf16x3"
+            peak = 2500.0 / 3.0 if split else 157.3  # three bf16 MFMAs per product against the ~2.5 PF dense bf16 peak
             line["roofline"] = {
-                "kernel": "dense_batched_kernel (K2: sample pass + threshold + filter pass)", "bound": "mfma",
-                "achieved": tf, "peak": 157.3, "unit": "TFLOP/s", "frac": tf / 157.3, "traffic": None,
+                "kernel": ("dense_batched_split_kernel" if split else "dense_batched_kernel")
+                          + " (K2: sample pass + threshold + filter pass)", "bound": "mfma",
+                "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak, "traffic": None,
                 "algorithmic_flop_per_launch": flop, "avg_launch_ms": scan_avg_ms, "launches": scan_n,
-                "note": "f32-in/f32-acc v_mfma_f32_32x32x2_f32; the timed span includes the sampled-threshold pre-pass, "
-                        "the flop count does not"}
-            line["dtype"] = "f32"
+                "note": ("bf16 x 3 split products (hi.hi + hi.lo + lo.hi), f32 accumulate; peak = 2.5 PF / 3; scores "
+                         "within ~1e-6 of f32 (bound 3e-5), not bit-equal" if split else
+                         "f32-in/f32-acc v_mfma_f32_32x32x2_f32") + "; the timed span includes the sampled-threshold "
+                        "pre-pass, the flop count does not"}
+            line["dtype"] = "bf16x3" if split else "f32"
         if not sharded and not args.no_cpu_baseline and not batched:
             line["cpu_baseline"] = cpu_baseline(args, E, Q, post, idf if hybrid else None,
                                                 avgdl if hybrid else None, term_lists, out, cnt, hybrid, K, TOPN,

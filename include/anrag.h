@@ -146,6 +146,13 @@ int anrag_dense_search_batch_device(anrag_index *idx, const float *d_queries, in
                                     int32_t k, const uint32_t *d_allow_bits, anrag_candidate *d_out,
                                     int32_t *d_flag);
 
+/* Arithmetic of the batched path.  0 (default): exact f32 products and sums on the f32 matrix cores.
+ * 1: split-precision -- every operand as hi + lo bf16, three bf16 MFMAs per product (hi.hi + hi.lo + lo.hi),
+ * f32 accumulation: scores within ~3e-5 of the f32 result for unit-norm vectors (inside the 1e-4 bar, not
+ * bit-equal), the pass HBM/MFMA balanced instead of MFMA-bound.  Applies to passes of any size (the query
+ * block is padded to 256). */
+int anrag_set_batched_precision(anrag_index *idx, int32_t mode);
+
 /* All N scores of one query (what search_engine.py:81 materialises), for tests
  * and for callers that post-process scores themselves.  out: host, n_rows fp32. */
 int anrag_dense_scores(anrag_index *idx, const float *query, float *out_scores);

@@ -10,11 +10,13 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
 d = int(sys.argv[2]) if len(sys.argv) > 2 else 768
 nq = int(sys.argv[3]) if len(sys.argv) > 3 else 256
 k = int(sys.argv[4]) if len(sys.argv) > 4 else 10
+prec = sys.argv[5] if len(sys.argv) > 5 else "f32"
 dev = torch.device("cuda", 0)
 E = synth.dense_corpus(n, d, 1234, dev)
 Q, rows = synth.dense_queries(E, nq, 4321)
 torch.cuda.synchronize()
 idx = Index(0); idx.dense_load((E.data_ptr(), n, d))
+idx.set_batched_precision(prec)
 lib = nat.load_library()
 out = torch.zeros((nq, k, 2), dtype=torch.int64, device=dev)
 flag = torch.zeros(nq, dtype=torch.int32, device=dev)
@@ -33,5 +35,5 @@ idx.sync(); wall = (time.perf_counter() - t0) / iters
 ms, launches = idx.profile_read(nat.KERNEL_DENSE_BATCHED)
 ms /= launches
 flop = 2.0 * nq * n * d
-print(f"n={n} d={d} nq={nq} k={k}: wall/pass {wall*1e3:.3f} ms ({nq/wall:.0f} q/s)  GEMM passes (sample+filter) {ms:.3f} ms "
+print(f"[{prec}] n={n} d={d} nq={nq} k={k}: wall/pass {wall*1e3:.3f} ms ({nq/wall:.0f} q/s)  GEMM passes (sample+filter) {ms:.3f} ms "
       f"-> {flop/ms/1e9:.1f} TFLOP/s on the full pass alone est., {flop/(ms*1e-3)/1e12/157.3*100:.1f}% of 157.3 TF")

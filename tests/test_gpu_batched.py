@@ -62,3 +62,33 @@ def test_overflowing_survivor_lists_fall_back():
         doc, score, count = idx.dense_search(q, 5)
         assert np.all(count == 5)
         assert np.all(doc == np.arange(5)[None, :])
+
+
+def test_split_precision_option(corpus):
+    """bf16 x 3 split products (opt-in): every score within 1e-4 of the f32 oracle (bound ~3e-5 for unit-norm rows),
+    rows identical outside near-ties, and the measured error is reported."""
+    from oracle import ref_search
+    from anrag.index import Index
+
+    e = corpus
+    n, d = e.shape
+    rng = np.random.default_rng(5)
+    nq, k = 200, 10
+    rows = rng.integers(0, n, nq)
+    q = e[rows] + 0.05 * rng.standard_normal((nq, d), dtype=np.float32)
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    with Index(0) as idx:
+        idx.dense_load(e)
+        idx.set_batched_precision("bf16x3")
+        doc, score, count = idx.dense_search(q, k)
+        idx.set_batched_precision("f32")
+        doc32, score32, _ = idx.dense_search(q, k)
+    worst = 0.0
+    for qi in range(nq):
+        full = ref_search.dense_scores(q[qi], e)
+        want = ref_search.canonical_topk(full, k)
+        assert_ranking_matches(want, full[want], doc[qi], score[qi], 1e-4, full, f"bf16x3 q{qi}")
+        worst = max(worst, float(np.max(np.abs(full[doc[qi]] - score[qi]))))
+    assert worst <= 5e-5, worst
+    assert (doc == doc32).mean() > 0.99
+    print(f"bf16x3 max |score - f32 oracle| over {nq * k} results: {worst:.2e}")
