@@ -655,8 +655,9 @@ static int hybrid_enqueue(anrag_index *idx, TailMode tail, const float *d_query,
     }
     hipStream_t T = tail == kTailFuse ? S : F;
     if (use_bm25) {
-        // the BM25 partition lists are single-buffered: this K3 must not start before the previous tail read them
-        if (T != S && idx->hyb_seq >= 2) ANRAG_HIP(hipStreamWaitEvent(S, idx->ev_fused[b ^ 1], 0));
+        // the BM25 partition lists are single-buffered: this K3 must not start before the previous query's tail
+        // (which may have run on another stream) has read them
+        if (idx->hyb_seq >= 2) ANRAG_HIP(hipStreamWaitEvent(S, idx->ev_fused[b ^ 1], 0));
         if ((rc = launch_bm25_lists(idx, S, d_terms, n_terms, k, d_allow_bm25, nullptr))) return rc;
         if (T != S) {
             ANRAG_HIP(hipEventRecord(idx->ev_bm25[b], S));

@@ -64,6 +64,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: libanrag has no CPU path")
+    if local_rank >= torch.cuda.device_count():
+        local_rank = 0  # the launcher narrowed this rank's visibility to one device
     # ANRAG_FORCE_SHARDED=1: take the sharded (all-gather) route even at world size 1 -- a rehearsal of the
     # N > 1 code path on a one-GPU box
     sharded = world > 1 or os.environ.get("ANRAG_FORCE_SHARDED") == "1"
@@ -74,8 +78,6 @@ def main():
                                 device_id=torch.device("cuda", local_rank))
     if world != args.gpus and rank == 0:
         print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: libanrag has no CPU path")
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
 
