@@ -305,7 +305,7 @@ static int batched_passes(anrag_index *idx, hipStream_t st, int32_t nq, int32_t 
         dense_batched_kernel<QW, true, false><<<grid_for(n_sample), Geo::kThreads, Geo::kLdsBytes, st>>>(
             idx->d_emb, idx->d_bq, n_qblocks, n, dim, nq, n_sample, stride, nullptr, idx->d_bsample, nullptr, nullptr, 0,
             nullptr, nullptr);
-    batched_threshold_kernel<<<kBQ, 64, 0, st>>>(idx->d_bsample, n_sample, k, idx->d_btau, idx->d_bcnt);
+    batched_threshold_kernel<<<nq, 64, 0, st>>>(idx->d_bsample, n_sample, k, idx->d_btau, idx->d_bcnt);
     if (allow)
         dense_batched_kernel<QW, false, true><<<grid_for(n), Geo::kThreads, Geo::kLdsBytes, st>>>(
             idx->d_emb, idx->d_bq, n_qblocks, n, dim, nq, n, 1, idx->d_btau, nullptr, idx->d_bcnt, cand, kCandCap,

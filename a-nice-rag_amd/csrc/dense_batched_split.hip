@@ -216,7 +216,7 @@ int batched_passes_split(anrag_index *idx, hipStream_t st, int32_t nq, int32_t k
     else
         dense_batched_split_kernel<true, false><<<grid_for(n_sample), kSplitThreads, kSplitLdsBytes, st>>>(
             idx->d_emb, qh, ql, dim, nq, n_sample, stride, nullptr, idx->d_bsample, nullptr, nullptr, 0, nullptr, nullptr);
-    batched_threshold_kernel<<<kBQ, 64, 0, st>>>(idx->d_bsample, n_sample, k, idx->d_btau, idx->d_bcnt);
+    batched_threshold_kernel<<<nq, 64, 0, st>>>(idx->d_bsample, n_sample, k, idx->d_btau, idx->d_bcnt);
     if (allow)
         dense_batched_split_kernel<false, true><<<grid_for(n), kSplitThreads, kSplitLdsBytes, st>>>(
             idx->d_emb, qh, ql, dim, nq, n, 1, idx->d_btau, nullptr, idx->d_bcnt, cand, kCandCap, idx->d_dense_src, allow);

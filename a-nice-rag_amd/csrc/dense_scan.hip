@@ -222,7 +222,7 @@ int launch_dense_scan(anrag_index *idx, hipStream_t st, const float *d_query, in
     {
         LaunchTimer t(idx, ANRAG_KERNEL_DENSE_SCAN, st);
         bool done = true;
-        if (d % 256 == 0 && d / 256 <= 8) {
+        if (d % 256 == 0 && d / 256 <= 16) {
             switch (d / 256) {
                 case 1: launch_scan<64, 1>(grid, st, idx, d_query, k, allow, d_scores_out, blk_s, blk_r); break;
                 case 2: launch_scan<64, 2>(grid, st, idx, d_query, k, allow, d_scores_out, blk_s, blk_r); break;
@@ -230,6 +230,8 @@ int launch_dense_scan(anrag_index *idx, hipStream_t st, const float *d_query, in
                 case 4: launch_scan<64, 4>(grid, st, idx, d_query, k, allow, d_scores_out, blk_s, blk_r); break;
                 case 6: launch_scan<64, 6>(grid, st, idx, d_query, k, allow, d_scores_out, blk_s, blk_r); break;
                 case 8: launch_scan<64, 8>(grid, st, idx, d_query, k, allow, d_scores_out, blk_s, blk_r); break;
+                case 12: launch_scan<64, 12>(grid, st, idx, d_query, k, allow, d_scores_out, blk_s, blk_r); break;  // 3072
+                case 16: launch_scan<64, 16>(grid, st, idx, d_query, k, allow, d_scores_out, blk_s, blk_r); break;  // 4096
                 default: done = false;
             }
         } else if (d % 128 == 0 && d / 128 <= 8) {

@@ -62,8 +62,8 @@ def test_golden_dense_vectors(Index):
     assert checked > 60
 
 
-@pytest.mark.parametrize("n,d", [(5000, 768), (3001, 384), (1000, 1024), (777, 2048), (2000, 192), (500, 100),
-                                 (64, 8), (3, 768), (1, 384)])
+@pytest.mark.parametrize("n,d", [(5000, 768), (3001, 384), (1000, 1024), (777, 2048), (600, 3072), (300, 4096),
+                                 (900, 1536), (2000, 192), (500, 100), (64, 8), (3, 768), (1, 384)])
 def test_random_dense_vs_oracle(Index, n, d):
     from oracle import ref_search
 
