@@ -197,7 +197,7 @@ int anrag_index_create(int device, anrag_index **out) {
     hipError_t e = hipStreamCreateWithFlags(&idx->own_primary, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&idx->own_secondary, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&idx->own_fusion, hipStreamNonBlocking);
-    for (int b = 0; b < 2 && e == hipSuccess; ++b) {
+    for (int b = 0; b < kPipeSlots && e == hipSuccess; ++b) {
         e = hipEventCreateWithFlags(&idx->ev_scan[b], hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&idx->ev_bm25[b], hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&idx->ev_fused[b], hipEventDisableTiming);
@@ -243,7 +243,7 @@ int anrag_index_destroy(anrag_index *idx) {
         free_batched(idx);
         if (idx->h_pinned) (void)hipHostFree(idx->h_pinned);
         for (hipEvent_t e : idx->event_pool) (void)hipEventDestroy(e);
-        for (int b = 0; b < 2; ++b) {
+        for (int b = 0; b < kPipeSlots; ++b) {
             hipEvent_t evs[] = {idx->ev_scan[b], idx->ev_bm25[b], idx->ev_fused[b]};
             for (hipEvent_t ev : evs)
                 if (ev) (void)hipEventDestroy(ev);
@@ -313,25 +313,30 @@ int anrag_dense_load(anrag_index *idx, const float *embeddings, int64_t n_rows, 
     }
     idx->dense_doc_base = doc_id_base;
     if (!idx->d_blk_score_f32) {
-        if ((rc = dev_alloc(idx, &idx->d_blk_score_f32, (int64_t)2 * kMaxScanBlocks * kListLen))) return rc;
-        if ((rc = dev_alloc(idx, &idx->d_blk_row_a, (int64_t)2 * kMaxScanBlocks * kListLen))) return rc;
+        if ((rc = dev_alloc(idx, &idx->d_blk_score_f32, (int64_t)kPipeSlots * kMaxScanBlocks * kListLen))) return rc;
+        if ((rc = dev_alloc(idx, &idx->d_blk_row_a, (int64_t)kPipeSlots * kMaxScanBlocks * kListLen))) return rc;
     }
     if ((rc = ensure_query_buffer(idx, (int64_t)64 * dim))) return rc;
     return ANRAG_OK;
 }
 
+static int hybrid_enqueue(anrag_index *idx, TailMode tail, const float *d_query, const int32_t *d_terms,
+                          int32_t n_terms, int32_t k, double w_dense, double w_bm25, double wrrf_k, int32_t top_n,
+                          const uint32_t *d_allow_dense, const uint32_t *d_allow_bm25, anrag_candidate *d_out,
+                          int32_t *d_count);
+
 int anrag_dense_search_device(anrag_index *idx, const float *d_queries, int32_t n_queries, int32_t k,
                               const uint32_t *d_allow_bits, anrag_candidate *d_out) {
     ANRAG_ENTER(idx);
-    if (int rc0 = settle_pipeline(idx)) return rc0;
-    if (int rc0 = settle_pipeline(idx)) return rc0;
     ANRAG_REQUIRE(idx->d_emb != nullptr, "dense search before anrag_dense_load");
     ANRAG_REQUIRE(d_queries && d_out, "NULL operand");
     ANRAG_REQUIRE(n_queries > 0, "n_queries must be positive");
     ANRAG_REQUIRE(k > 0 && k <= ANRAG_FUSED_K_MAX, "device path serves 1 <= k <= %d (got %d)", ANRAG_FUSED_K_MAX, k);
+    // the dense-only member of the query pipeline: scans back to back on the primary stream, each query's list
+    // merge on the fusion stream under the next scan (results complete in fusion-stream order)
     for (int32_t qi = 0; qi < n_queries; ++qi) {
-        int rc = launch_dense_topk(idx, idx->primary, d_queries + (int64_t)qi * idx->dim, k, d_allow_bits,
-                                   d_out + (int64_t)qi * k, nullptr);
+        int rc = hybrid_enqueue(idx, kTailCandidates, d_queries + (int64_t)qi * idx->dim, nullptr, 0, k, 1.0, 0.0, 0.0, 0,
+                                d_allow_bits, nullptr, d_out + (int64_t)qi * k, nullptr);
         if (rc) return rc;
     }
     return ANRAG_OK;
@@ -627,14 +632,16 @@ int anrag_wrrf_device(anrag_index *idx, const anrag_candidate *d_dense, int32_t 
 }
 
 // ------------------------------------------------------------------ fused hybrid query
-// dense on `primary`, BM25 on `secondary`, WRRF on `primary` after the join; nothing syncs the host.
-// One hybrid query through the stream pipeline (no host sync), THREE launches:
-//   primary    K1 scan                      -> dense block lists, set b
-//   secondary  K3 BM25                      -> BM25 partition lists
+// One hybrid query through the stream pipeline, THREE launches:
+//   primary    K1 scan                      -> dense block lists of the query's slot
+//   secondary  K3 BM25                      -> BM25 partition lists of the slot
 //   tail       (fused: secondary; candidates: fusion stream) waits for the scan, then ONE kernel merges both
 //              list sets and either fuses (WRRF + top-n -> d_out) or writes both candidate lists to d_out
-// b = sequence number & 1: the dense block lists are double-buffered, so back-to-back queries keep the scans
-// adjacent on `primary` and everything else of query i runs under the scan of query i+1.
+// slot = sequence number % kPipeSlots.  Back-to-back queries keep the scans adjacent on `primary` with NO
+// event wait between them (a barrier packet in front of every scan cost 5-6 us per query on MI355X); everything
+// else of query i runs under the scans of the following queries.  The only backpressure is on the host: before
+// a slot is reused the call waits until the tail that last read it has finished, so at most kPipeSlots queries
+// are in flight and the device never has to be told to wait for a buffer.
 static int hybrid_enqueue(anrag_index *idx, TailMode tail, const float *d_query, const int32_t *d_terms,
                           int32_t n_terms, int32_t k, double w_dense, double w_bm25, double wrrf_k, int32_t top_n,
                           const uint32_t *d_allow_dense, const uint32_t *d_allow_bm25, anrag_candidate *d_out,
@@ -643,22 +650,19 @@ static int hybrid_enqueue(anrag_index *idx, TailMode tail, const float *d_query,
     const bool use_dense = idx->d_emb != nullptr && (tail == kTailCandidates || w_dense > 0.0);
     ANRAG_REQUIRE(use_dense || use_bm25, "hybrid search with neither a dense nor a BM25 leg");
     hipStream_t P = idx->primary, S = idx->secondary, F = idx->fusion;
-    const int b = (int)(idx->hyb_seq & 1);
-    const bool reuse = idx->hyb_seq >= 2;
+    const int b = (int)(idx->hyb_seq % kPipeSlots);
+    if (idx->hyb_seq >= (uint64_t)kPipeSlots && hipEventQuery(idx->ev_fused[b]) != hipSuccess)
+        ANRAG_HIP(hipEventSynchronize(idx->ev_fused[b]));
     idx->hyb_seq++;
     idx->hyb_outstanding = true;
     int rc;
     if (use_dense) {
-        if (reuse) ANRAG_HIP(hipStreamWaitEvent(P, idx->ev_fused[b], 0));  // the tail two queries back has read set b
         if ((rc = launch_dense_scan(idx, P, d_query, k, d_allow_dense, nullptr, b))) return rc;
         ANRAG_HIP(hipEventRecord(idx->ev_scan[b], P));
     }
     hipStream_t T = tail == kTailFuse ? S : F;
     if (use_bm25) {
-        // the BM25 partition lists are single-buffered: this K3 must not start before the previous query's tail
-        // (which may have run on another stream) has read them
-        if (idx->hyb_seq >= 2) ANRAG_HIP(hipStreamWaitEvent(S, idx->ev_fused[b ^ 1], 0));
-        if ((rc = launch_bm25_lists(idx, S, d_terms, n_terms, k, d_allow_bm25, nullptr))) return rc;
+        if ((rc = launch_bm25_lists(idx, S, d_terms, n_terms, k, d_allow_bm25, nullptr, b))) return rc;
         if (T != S) {
             ANRAG_HIP(hipEventRecord(idx->ev_bm25[b], S));
             ANRAG_HIP(hipStreamWaitEvent(T, idx->ev_bm25[b], 0));

@@ -332,22 +332,24 @@ int bm25_load(anrag_index *idx, const int64_t *indptr, int64_t n_terms, const in
     if (idx->d_blk_row_b) (void)hipFree(idx->d_blk_row_b);
     idx->d_blk_score_f64 = nullptr;
     idx->d_blk_row_b = nullptr;
-    ANRAG_HIP(hipMalloc(reinterpret_cast<void **>(&idx->d_blk_score_f64), (size_t)idx->n_parts * kListLen * 8));
-    ANRAG_HIP(hipMalloc(reinterpret_cast<void **>(&idx->d_blk_row_b), (size_t)idx->n_parts * kListLen * 4));
+    ANRAG_HIP(hipMalloc(reinterpret_cast<void **>(&idx->d_blk_score_f64), (size_t)kPipeSlots * idx->n_parts * kListLen * 8));
+    ANRAG_HIP(hipMalloc(reinterpret_cast<void **>(&idx->d_blk_row_b), (size_t)kPipeSlots * idx->n_parts * kListLen * 4));
     return ANRAG_OK;
 }
 
 // K3 only: per-partition lists (or every score) are left in HBM; the tail kernel finishes the top-k
 int launch_bm25_lists(anrag_index *idx, hipStream_t st, const int32_t *d_terms, int32_t n_terms, int32_t k,
-                      const uint32_t *d_allow_bits, double *d_scores_out) {
+                      const uint32_t *d_allow_bits, double *d_scores_out, int set) {
     const uint32_t *allow = idx->d_bm25_src ? d_allow_bits : nullptr;
+    double *blk_s = idx->d_blk_score_f64 + (int64_t)set * idx->n_parts * kListLen;
+    uint32_t *blk_r = idx->d_blk_row_b + (int64_t)set * idx->n_parts * kListLen;
     {
         LaunchTimer t(idx, ANRAG_KERNEL_BM25, st);
 #define ANRAG_BM25(F, S)                                                                                          \
     bm25_kernel<F, S><<<idx->n_parts, kBm25Threads, 0, st>>>(                                                      \
         idx->d_indptr, idx->d_post_doc, idx->d_post_impact, idx->d_idf, idx->d_part_slot, idx->d_part_ptr,        \
         idx->n_parts, idx->part_docs, idx->n_docs, idx->n_terms, d_terms, n_terms, k, idx->d_bm25_src, allow,     \
-        idx->d_blk_score_f64, idx->d_blk_row_b, d_scores_out)
+        blk_s, blk_r, d_scores_out)
         if (d_scores_out) {
             if (allow) ANRAG_BM25(true, true); else ANRAG_BM25(false, true);
         } else {
@@ -361,7 +363,7 @@ int launch_bm25_lists(anrag_index *idx, hipStream_t st, const int32_t *d_terms, 
 
 int launch_bm25(anrag_index *idx, hipStream_t st, const int32_t *d_terms, int32_t n_terms, int32_t k,
                 const uint32_t *d_allow_bits, anrag_candidate *d_out, double *d_scores_out) {
-    int rc = launch_bm25_lists(idx, st, d_terms, n_terms, k, d_allow_bits, d_scores_out);
+    int rc = launch_bm25_lists(idx, st, d_terms, n_terms, k, d_allow_bits, d_scores_out, 0);
     if (rc || d_scores_out) return rc;
     return launch_tail(idx, st, 0, /*dense*/ false, /*bm25*/ true, k, kTailCandidates, 0, 0, 0, 0, d_out, nullptr);
 }

@@ -17,6 +17,7 @@ constexpr int kWave = 64;            // CDNA wavefront
 constexpr int kListLen = 64;         // one top-k slot per lane (ANRAG_FUSED_K_MAX)
 constexpr int kScanThreads = 256;    // 4 waves: one scan workgroup per CU (sweep: profiles/r01_scan_config_sweep.txt)
 constexpr int kScanWaves = kScanThreads / kWave;
+constexpr int kPipeSlots = 8;      // queries in flight in the hybrid pipeline (list sets, events)
 constexpr int kMaxScanBlocks = 256;  // one per CU; also bounds the final merge fan-in
 constexpr uint32_t kNoRow = 0xFFFFFFFFu;
 
@@ -56,10 +57,11 @@ struct anrag_index {
     // sharded path, the caller's collectives).  A hybrid query touches all three and never syncs the host.
     hipStream_t own_primary = nullptr, own_secondary = nullptr, own_fusion = nullptr;
     hipStream_t primary = nullptr, secondary = nullptr, fusion = nullptr;
-    // hybrid pipeline, double-buffered on (query sequence number & 1)
-    hipEvent_t ev_scan[2] = {nullptr, nullptr};    // scan of buffer b finished (primary)
-    hipEvent_t ev_bm25[2] = {nullptr, nullptr};    // BM25 candidates of buffer b ready (secondary)
-    hipEvent_t ev_fused[2] = {nullptr, nullptr};   // candidate slots of buffer b consumed (fusion)
+    // hybrid pipeline: slot = query sequence number % kPipeSlots owns one set of dense block lists, one set
+    // of BM25 partition lists and three events
+    hipEvent_t ev_scan[anrag::kPipeSlots] = {};    // scan of the slot finished (primary)
+    hipEvent_t ev_bm25[anrag::kPipeSlots] = {};    // BM25 lists of the slot ready (secondary)
+    hipEvent_t ev_fused[anrag::kPipeSlots] = {};   // tail of the slot finished: its lists may be overwritten
     uint64_t hyb_seq = 0;
     bool hyb_outstanding = false;
 
@@ -86,9 +88,9 @@ struct anrag_index {
     double bm25_k1 = 0, bm25_b = 0, bm25_avgdl = 0;
 
     // ---- workspaces (sized at load; reused by every query on the stream that owns them)
-    float *d_blk_score_f32 = nullptr;  // [2][kMaxScanBlocks][kListLen]  (two sets: hybrid pipeline)
+    float *d_blk_score_f32 = nullptr;  // [kPipeSlots][kMaxScanBlocks][kListLen]
     uint32_t *d_blk_row_a = nullptr;
-    double *d_blk_score_f64 = nullptr;  // BM25 per-partition lists
+    double *d_blk_score_f64 = nullptr;  // BM25 per-partition lists [kPipeSlots][n_parts][kListLen]
     uint32_t *d_blk_row_b = nullptr;
     float *d_query = nullptr;           // staged queries
     int64_t query_cap = 0;
@@ -161,7 +163,7 @@ int dense_scan_grid(const anrag_index *idx);
 int launch_dense_scan(anrag_index *idx, hipStream_t stream, const float *d_query, int32_t k,
                       const uint32_t *d_allow_bits, float *d_scores_out, int set);
 int launch_bm25_lists(anrag_index *idx, hipStream_t st, const int32_t *d_terms, int32_t n_terms, int32_t k,
-                      const uint32_t *d_allow_bits, double *d_scores_out);
+                      const uint32_t *d_allow_bits, double *d_scores_out, int set);
 // Tail of a query, ONE launch (tail.hip): merge the dense block lists of set `set` and/or the BM25 partition
 // lists into per-modality top-k, then either write both lists (kTailCandidates: d_out[0..k) dense,
 // [k..2k) BM25; with one modality only its k records at d_out[0..k)) or fuse them (kTailFuse: WRRF + top_n).

@@ -123,8 +123,8 @@ int launch_tail(anrag_index *idx, hipStream_t st, int set, bool use_dense, bool 
     a.n_dense = use_dense ? dense_scan_grid(idx) : 0;
     a.dense_doc = idx->d_dense_doc;
     a.dense_base = idx->dense_doc_base;
-    a.b_score = idx->d_blk_score_f64;
-    a.b_row = idx->d_blk_row_b;
+    a.b_score = idx->d_blk_score_f64 + (int64_t)set * idx->n_parts * kListLen;
+    a.b_row = idx->d_blk_row_b + (int64_t)set * idx->n_parts * kListLen;
     a.n_bm25 = use_bm25 ? idx->n_parts : 0;
     a.bm25_doc = idx->d_bm25_doc;
     a.bm25_base = idx->bm25_doc_base;

@@ -128,9 +128,10 @@ int anrag_dense_search(anrag_index *idx, const float *queries, int32_t n_queries
                        const uint8_t *allow_source, int32_t n_sources, int64_t *out_doc,
                        float *out_score, int32_t *out_count);
 
-/* Same, all operands in HBM, enqueued on the primary stream, no host sync:
- * d_out is n_queries x k anrag_candidate.  Used for back-to-back query streams
- * and for the sharded path (the output is the all-gather send buffer).
+/* Same, all operands in HBM, no host sync: d_out is n_queries x k
+ * anrag_candidate.  The scans run back to back on the primary stream, each
+ * query's list merge on the fusion stream under the next scan: results are
+ * complete in fusion-stream order (anrag_index_sync waits for everything).
  * d_allow_bits: nullable device bitmap, bit s of word s/32 = source s allowed. */
 int anrag_dense_search_device(anrag_index *idx, const float *d_queries, int32_t n_queries,
                               int32_t k, const uint32_t *d_allow_bits, anrag_candidate *d_out);
@@ -216,9 +217,10 @@ int anrag_hybrid_search(anrag_index *idx, const float *query, const int32_t *ter
  * distinct ids) records in fused order, *d_count that number, complete in
  * secondary-stream order (anrag_index_sync waits for all streams).
  * Back-to-back queries pipeline: the scans stay adjacent on the primary stream;
- * BM25 and the fusion of query i run under the scan of query i+1 (candidate
- * slots are double-buffered internally).  Three launches per query: K1 and K3
- * finish their own top-k (last-workgroup merge), K5 fuses. */
+ * BM25 and the tail of query i run under the scans of the following queries.
+ * Three launches per query: K1, K3 and one tail kernel (list merges + WRRF).
+ * At most 8 queries are in flight per index: the call blocks on the HOST (never
+ * on the device) until the query 8 back has finished with its buffers. */
 int anrag_hybrid_search_device(anrag_index *idx, const float *d_query, const int32_t *d_term_ids,
                                int32_t n_terms, int32_t similarity_k, double w_dense,
                                double w_bm25, double wrrf_k, int32_t top_n,
