@@ -51,6 +51,9 @@ def parse_args():
                     help="--workload batched: exact f32 MFMA (default) or opt-in split-precision bf16 x 3 products")
     ap.add_argument("--exchange-group", type=int, default=4,
                     help="N > 1: in-flight queries that share one all-gather (each is still scanned alone)")
+    ap.add_argument("--filter", action="store_true",
+                    help="single-GPU diagnostic: source-prefix filter as retrieval_eval.py:280 passes it ('CG,NG'); rows "
+                         "carry one of 300 source ids, 15 %% of them outside the filter (SURVEY.md 8d)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-queries", type=int, default=3, help="queries of the bounded CPU sample")
     return ap.parse_args()
@@ -100,7 +103,17 @@ def main():
     E = synth.dense_corpus(n_local, args.dim, 1234 + rank, device)
     idx = Index(local_rank)
     torch.cuda.synchronize()  # device-pointer operands must be complete: the library copies on its own stream
-    idx.dense_load((E.data_ptr(), n_local, args.dim), doc_id_base=lo)
+    src = allowed_rows = d_allow = None
+    if args.filter:
+        if sharded or batched:
+            raise SystemExit("--filter is a single-GPU batch=1 diagnostic")
+        src = ((np.arange(n_local, dtype=np.int64) + lo) % 300).astype(np.uint16)  # 300 guideline codes, cyclic
+        allow = np.zeros(65536, np.uint8)
+        allow[45:300] = 1  # ids 0..44 = the ~15 % QS/TA/PH sources the 'CG,NG' filter drops
+        allowed_rows = allow[src].astype(bool)
+        # 2048 words, bit (s % 32) of word s / 32 = source s allowed
+        d_allow = torch.from_numpy(np.packbits(allow, bitorder="little").view(np.int32).copy()).to(device)
+    idx.dense_load((E.data_ptr(), n_local, args.dim), source_id=src, doc_id_base=lo)
     if batched:
         idx.set_batched_precision(args.batch_precision)
     # queries: planted next to rows of rank 0's shard, identical on every rank
@@ -121,7 +134,7 @@ def main():
         torch.cuda.synchronize()
         idx.bm25_load(post["indptr"], (post["post_doc"].data_ptr(), post["post_doc"].numel()),
                       (post["post_tf"].data_ptr(), post["post_tf"].numel()), idf, post["doc_len"], avgdl,
-                      synth.BM25_K1, synth.BM25_B, doc_id_base=lo)
+                      synth.BM25_K1, synth.BM25_B, source_id=src, doc_id_base=lo)
         term_lists = synth.bm25_queries(post, args.queries, 99) if rank == 0 else []
     # query term ids as one padded device tensor; rank 0's are broadcast so that every rank asks the same query
     MAX_TERMS = 16
@@ -146,18 +159,19 @@ def main():
     if not sharded:
         out = torch.zeros((args.queries, TOPN, 2), dtype=torch.int64, device=device)
         cnt = torch.zeros(args.queries, dtype=torch.int32, device=device)
+        allow_ptr = d_allow.data_ptr() if d_allow is not None else None
 
         def step(i):
             qi = i % args.queries
             if hybrid:
                 nat.check(lib.anrag_hybrid_search_device(
                     idx.handle, Q[qi].data_ptr(), T[qi].data_ptr(), n_terms[qi], K, W_DENSE, W_BM25, WRRF_K, TOPN,
-                    None, None, out[qi].data_ptr(), cnt[qi:].data_ptr()))
+                    allow_ptr, allow_ptr, out[qi].data_ptr(), cnt[qi:].data_ptr()))
             elif batched:  # one step = one pass of args.batch queries
                 nat.check(lib.anrag_dense_search_batch_device(idx.handle, Q.data_ptr(), args.batch, TOPN, None,
                                                               out.data_ptr(), cnt.data_ptr()))
             else:
-                nat.check(lib.anrag_dense_search_device(idx.handle, Q[qi].data_ptr(), 1, TOPN, None,
+                nat.check(lib.anrag_dense_search_device(idx.handle, Q[qi].data_ptr(), 1, TOPN, allow_ptr,
                                                         out[qi].data_ptr()))
 
         def finish():
@@ -204,10 +218,26 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # single-query latency (SURVEY.md 8d asks for p50/p99 next to the throughput): one query in flight,
+    # enqueue -> all streams idle, host clock.  Outside the timed region.
+    latency = None
+    if not sharded and not batched:
+        lat = []
+        for i in range(200):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            step(i)
+            finish()
+            lat.append((time.perf_counter() - t1) * 1e6)
+        lat = np.sort(np.asarray(lat[20:]))
+        latency = {"p50": float(lat[len(lat) // 2]), "p99": float(lat[min(len(lat) - 1, int(len(lat) * 0.99))]),
+                   "n": int(len(lat)), "what": "one query in flight: enqueue + wait for its result, host clock"}
+
     # ------------------------------------------------------------------ report (rank 0)
     if rank == 0:
         scan_avg_ms = scan_ms / max(scan_n, 1)
-        alg_bytes = n_local * args.dim * 4  # N*D*4 per query (this rank's rows)
+        # N*D*4 per query (this rank's rows), + N*2 with a filter
+        alg_bytes = n_local * args.dim * 4 + (n_local * 2 if args.filter else 0)
         achieved = alg_bytes / (scan_avg_ms * 1e-3) / 1e9 if scan_n else 0.0
         traffic = None
         pmc = os.path.join(REPO, "profiles", "pmc_dense_scan.json")
@@ -245,7 +275,7 @@ def main():
                 "similarity_k": K, "top_n": TOPN, "wrrf_k": WRRF_K, "weights": [W_DENSE, W_BM25],
                 "sharding": ("rows/%d + RCCL all-gather of per-shard top-k, %d queries per all-gather"
                              % (world, args.exchange_group)) if sharded else "none",
-                "bm25_arith": "f64",
+                "bm25_arith": "f64", "source_filter": "CG,NG-shaped: 255 of 300 source ids allowed" if args.filter else None,
             },
             "roofline": {
                 "kernel": "dense_scan_kernel (K1)", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
@@ -254,6 +284,8 @@ def main():
             },
             "index_build_s": build_s,
         }
+        if latency:
+            line["latency_us"] = latency
         if batched:
             flop = 2.0 * args.batch * n_local * args.dim  # 2*Q*N*D per pass
             tf = flop / (scan_avg_ms * 1e-3) / 1e12 if scan_n else 0.0
@@ -272,7 +304,7 @@ def main():
         if not sharded and not args.no_cpu_baseline and not batched:
             line["cpu_baseline"] = cpu_baseline(args, E, Q, post, idf if hybrid else None,
                                                 avgdl if hybrid else None, term_lists, out, cnt, hybrid, K, TOPN,
-                                                (W_DENSE, W_BM25, WRRF_K))
+                                                (W_DENSE, W_BM25, WRRF_K), allowed_rows)
             line["recall_at_10"] = line["cpu_baseline"].pop("niceqa_recall_at_10")
         print(json.dumps(line), flush=True)
     if sharded:
@@ -280,7 +312,7 @@ def main():
         dist.destroy_process_group()
 
 
-def cpu_baseline(args, E, Q, post, idf, avgdl, term_lists, gpu_out, gpu_cnt, hybrid, K, TOPN, fusion):
+def cpu_baseline(args, E, Q, post, idf, avgdl, term_lists, gpu_out, gpu_cnt, hybrid, K, TOPN, fusion, allowed=None):
     """The reference-shaped CPU path (oracle = port of src/search_engine.py) timed on this box's host
     cores over a bounded sample of the same queries, and used as the parity check of the GPU results."""
     import torch
@@ -301,6 +333,8 @@ def cpu_baseline(args, E, Q, post, idf, avgdl, term_lists, gpu_out, gpu_cnt, hyb
         t0 = time.perf_counter()
         emb = np.stack(rows)  # search_engine.py:80 -- re-materialised on every query
         sims = np.dot(q_host[qi].reshape(1, -1), emb.T).flatten()
+        if allowed is not None:  # the reference filters the DataFrame first (pandas str ops, not timed here)
+            sims = np.where(allowed, sims, -np.inf)
         top = ref_search.numpy_topk_idiom(sims, K)
         dense_list = top.tolist()
         t_stack_path = time.perf_counter() - t0
@@ -312,7 +346,7 @@ def cpu_baseline(args, E, Q, post, idf, avgdl, term_lists, gpu_out, gpu_cnt, hyb
         if hybrid:
             scores = ref_bm25.csr_get_scores(post["indptr"], post_doc, post_tf, idf, post["doc_len"], avgdl,
                                              1.7, 0.83, term_lists[qi].tolist())
-            bm_list = ref_search.canonical_topk(scores, K).tolist()
+            bm_list = ref_search.canonical_topk(scores, K, allowed).tolist()
             fused = ref_search.weighted_reciprocal_rank_fusion(
                 [(dense_list, "dense"), (bm_list, "BM25")], {"dense": w_dense, "BM25": w_bm25}, int(wrrf_k))[:TOPN]
             want_ids = [i for i, _ in fused]
