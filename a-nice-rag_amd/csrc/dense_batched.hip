@@ -98,30 +98,32 @@ __global__ __launch_bounds__(BatchGeom<QW>::kThreads, 2) void dense_batched_kern
         pq[i] = queries + (int64_t)(qbase + (f >> 3)) * dim + (f & 7) * 4;
     }
     point_rows();
-    auto load_stage = [&]() {
-#pragma unroll
-        for (int i = 0; i < NE; ++i) stage_e[i] = *reinterpret_cast<const f32x4 *>(pe[i] + ld_ks * kBK);
-#pragma unroll
-        for (int i = 0; i < NQ; ++i) stage_q[i] = *reinterpret_cast<const f32x4 *>(pq[i] + ld_ks * kBK);
+    // one staged float4 (item j < NE: corpus tile, else query tile): global -> register, register -> LDS
+    auto load_item = [&](int j) {
+        if (j < NE) stage_e[j] = *reinterpret_cast<const f32x4 *>(pe[j] + ld_ks * kBK);
+        else stage_q[j - NE] = *reinterpret_cast<const f32x4 *>(pq[j - NE] + ld_ks * kBK);
+    };
+    auto advance_cursor = [&]() {
         if (++ld_ks == ksteps) {
             ld_ks = 0;
             ld_tile += tile_step;
             point_rows();
         }
     };
-    auto store_stage = [&](int buf) {
+    auto store_item = [&](int j, int buf) {
         float *es = lds + buf * kBufFloats;
-        float *qs = es + kBM * kLdk;
+        const int f = tid + (j < NE ? j : j - NE) * kBatchThreads;
+        float *dst = (j < NE ? es : es + kBM * kLdk) + (f >> 3) * kLdk + (f & 7) * 4;
+        *reinterpret_cast<f32x4 *>(dst) = j < NE ? stage_e[j] : stage_q[j - NE];
+    };
+    auto load_stage = [&]() {
 #pragma unroll
-        for (int i = 0; i < NE; ++i) {
-            const int f = tid + i * kBatchThreads;
-            *reinterpret_cast<f32x4 *>(es + (f >> 3) * kLdk + (f & 7) * 4) = stage_e[i];
-        }
+        for (int j = 0; j < NE + NQ; ++j) load_item(j);
+        advance_cursor();
+    };
+    auto store_stage = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < NQ; ++i) {
-            const int f = tid + i * kBatchThreads;
-            *reinterpret_cast<f32x4 *>(qs + (f >> 3) * kLdk + (f & 7) * 4) = stage_q[i];
-        }
+        for (int j = 0; j < NE + NQ; ++j) store_item(j, buf);
     };
 
     f32x16 acc[2][2];
@@ -133,9 +135,10 @@ __global__ __launch_bounds__(BatchGeom<QW>::kThreads, 2) void dense_batched_kern
             for (int r = 0; r < 16; ++r) acc[ti][tj][r] = 0.f;
 
     // Staging pipeline, two steps deep: the registers always hold step it+1 while step it is being multiplied.
-    // At the top of step it they are written to the OTHER LDS buffer (free since the barrier that closed step
-    // it-1) and re-loaded with step it+2 -- both under this step's MFMAs -- so the barrier at the bottom waits
-    // for matrix work only, never for a load or an LDS write.
+    // During step it they are written to the OTHER LDS buffer (free since the barrier that closed step it-1) and
+    // re-loaded with step it+2.  Both are dealt out ONE instruction at a time between this step's MFMAs: a wave
+    // issues in order, and the two waves of a SIMD leave every barrier together, so a block of staging code at
+    // the top of the step left the matrix pipe idle for its whole length.
     if (total > 0) {
         load_stage();
         store_stage(0);
@@ -146,8 +149,8 @@ __global__ __launch_bounds__(BatchGeom<QW>::kThreads, 2) void dense_batched_kern
     int cur_ks = 0;
     for (int64_t it = 0; it < total; ++it) {
         const int buf = (int)(it & 1);
-        if (it + 1 < total) store_stage(buf ^ 1);
-        if (it + 2 < total) load_stage();
+        // (stores and loads run on the last steps too -- the cursor clamps to the last row, nobody reads the
+        // buffer: a branch around them would make the compiler wait for vmcnt(0) at every slot)
         const float *es = lds + buf * kBufFloats + (rw * 64 + l31) * kLdk + lh * 4;
         const float *qs = lds + buf * kBufFloats + kBM * kLdk + (qw * 64 + l31) * kLdk + lh * 4;
         // operand fragments of k-group g+1 are read from LDS while the 16 MFMAs of group g issue (separate
@@ -170,12 +173,25 @@ __global__ __launch_bounds__(BatchGeom<QW>::kThreads, 2) void dense_batched_kern
             }
             __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of this group's MFMAs
 #pragma unroll
-            for (int s = 0; s < 4; ++s)
+            for (int s = 0; s < 4; ++s) {
 #pragma unroll
                 for (int ti = 0; ti < 2; ++ti)
 #pragma unroll
                     for (int tj = 0; tj < 2; ++tj)
                         acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][ti][s], fb[cur][tj][s], acc[ti][tj], 0, 0, 0);
+                // staging slots: (0,0..1) write last step's registers to LDS, (0,2..3) refill them -- as early in
+                // the step as the order store -> load allows, so a load has almost a whole step to land
+                if (g == 0) {
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int j = 0; j < NE + NQ; ++j) {
+                        if (s < 2 && j % 2 == s) store_item(j, buf ^ 1);
+                        if (s >= 2 && j % 2 == s - 2) load_item(j);
+                    }
+                    if (s == 3) advance_cursor();
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
         }
         if (++cur_ks == ksteps) {
             batched_tile_epilogue<SAMPLE, FILTER>(acc, cur_tile, rw, qw, qbase, l31, lh, my_tau, n_work, stride, nq,
