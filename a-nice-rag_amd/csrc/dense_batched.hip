@@ -32,7 +32,7 @@ constexpr int kLdk = kBK + 4;    // padded LDS row (floats)
 // QW = queries per workgroup.  256: one 8-wave workgroup per CU (2 waves per SIMD), the whole pass against each
 // corpus tile -- fewest staged bytes per MFMA, best for full passes.  128: 4-wave workgroups, two per CU; a pass of
 // <= 128 queries does half the matrix work instead of multiplying zero padding (measured, 1M x 768: 256 queries
-// 3.52 ms with QW=256 vs 3.65 ms with 2 x QW=128; 128 queries 2.02 ms with QW=128).
+// 3.24 ms with QW=256 vs 3.5 ms with 2 x QW=128; 128 queries 1.75 ms with QW=128).
 template <int QW>
 struct BatchGeom {
     static constexpr int kThreads = QW * 2;                 // waves = 2 (row halves) x QW/64 (query columns)
