@@ -59,6 +59,7 @@ _SIGNATURES = {
     "anrag_bm25_scores": [_p, _p, _i32, _p],
     "anrag_wrrf": [_p, _p, _p, _p, _i32, _f64, _i32, _p, _p, _p],
     "anrag_hybrid_search": [_p, _p, _p, _i32, _i32, _f64, _f64, _f64, _i32, _p, _i32, _p, _i32, _p, _p, _p],
+    "anrag_hybrid_search_batch": [_p, _p, _p, _p, _i32, _i32, _f64, _f64, _f64, _i32, _p, _i32, _p, _i32, _p, _p, _p],
     "anrag_merge_candidates_device": [_p, _p, _i32, _i32, _i64, _p],
     "anrag_hybrid_candidates_device": [_p, _p, _p, _i32, _i32, _p, _p, _p],
     "anrag_merge_fuse_device": [_p, _p, _i32, _i32, _i64, _f64, _f64, _f64, _i32, _i32, _p, _p],

@@ -202,6 +202,32 @@ class Index:
         m = int(count[0])
         return out_id[:m], out_score[:m]
 
+    def hybrid_search_batch(self, queries, term_lists: Sequence[Sequence[int]], similarity_k: int, w_dense: float,
+                            w_bm25: float, wrrf_k: float, top_n: int, allow_dense=None, allow_bm25=None):
+        """Many hybrid queries in one call through the device pipeline (`anrag_hybrid_search_batch`).
+        -> (ids [nq, top_n] int64 (-1 padded), fused scores [nq, top_n] float64, counts [nq] int32); row i equals
+        `hybrid_search(queries[i], term_lists[i], ...)`."""
+        q = _f32(queries)
+        if q.ndim == 1:
+            q = q[None, :]
+        nq = q.shape[0]
+        assert q.shape[1] == self.dim and len(term_lists) == nq
+        offsets = np.zeros(nq + 1, dtype=np.int64)
+        np.cumsum([len(t) for t in term_lists], out=offsets[1:])
+        terms = (np.concatenate([np.asarray(t, dtype=np.int32).reshape(-1) for t in term_lists]).astype(np.int32)
+                 if offsets[-1] else np.zeros(0, np.int32))
+        terms = np.ascontiguousarray(terms)
+        ad, nd = _allow_bytes(allow_dense)
+        ab, nb = _allow_bytes(allow_bm25)
+        out_id = np.empty((nq, top_n), np.int64)
+        out_score = np.empty((nq, top_n), np.float64)
+        count = np.zeros(nq, np.int32)
+        nat.check(self._lib.anrag_hybrid_search_batch(
+            self.handle, q.ctypes.data, nat.ptr(terms) if terms.size else None, offsets.ctypes.data, nq,
+            int(similarity_k), float(w_dense), float(w_bm25), float(wrrf_k), int(top_n), nat.ptr(ad), nd, nat.ptr(ab), nb,
+            out_id.ctypes.data, out_score.ctypes.data, count.ctypes.data))
+        return out_id, out_score, count
+
     # ------------------------------------------------------------------ measurement
     def profile(self, on, kernels=None, every: int = 1) -> None:
         """Bracket launches with HIP events: on=True times every kernel id, `kernels=[ids]` only those,

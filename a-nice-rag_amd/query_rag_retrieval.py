@@ -186,6 +186,70 @@ class RetrievalEvaluationSystem:
             logger.error(f"Error in retrieval processing: {e}")
             return []
 
+    def retrieve_documents_batch(self, queries: List[Dict], **params) -> List[List[str]]:
+        """`retrieve_documents` for a LIST of queries (no reference counterpart: retrieval_eval.py:51-84 loops).
+        Each element of `queries` holds the per-query arguments (`query_embeddings`, and `query_tokens` and/or
+        `query_text`); `params` are the remaining keyword arguments of `retrieve_documents`, shared by all.
+        Element i of the result is exactly `retrieve_documents(**queries[i], **params)`: requests inside the fused
+        route's envelope (one dense model + BM25, ids out, no rerank, similarity_k <= 64) go to the library as ONE
+        `anrag_hybrid_search_batch`, i.e. through the device pipeline with a single host sync; anything else is
+        answered by the per-query method."""
+        def one_by_one():
+            return [self.retrieve_documents(**q, **params) for q in queries]
+
+        if not queries or not self.fused or params.get("return_docs") or not params.get("use_hybrid_search", False):
+            return one_by_one()
+        similarity_k = params.get("similarity_k", 25)
+        common_sections_n = params.get("common_sections_n", 15)
+        info_source = params.get("info_source", "NICE")
+        model_weights = params.get("model_weights") or self.config.DEFAULT_MODEL_WEIGHTS.copy()
+        try:
+            for q in queries:
+                self._validate_inputs(q.get("query_embeddings"), similarity_k, common_sections_n, info_source)
+        except ValueError:
+            return one_by_one()  # let the per-query method raise where the reference raises
+        source_enum = InfoSource(info_source.lower())
+        embeddings_dict = self.embeddings_data.get(source_enum, {})
+        bm25_tuple = self.bm25_data.get(source_enum)
+        if not embeddings_dict or not bm25_tuple or similarity_k > 64:
+            return one_by_one()
+        bm25, bm25_sections, bm25_section_ids = bm25_tuple
+        if bm25 is None or model_weights.get("BM25", 0) <= 0:
+            return one_by_one()
+        keys = None
+        token_lists = []
+        for q in queries:
+            active = [key for key, _, _ in self.config.DENSE_MODELS
+                      if embeddings_dict.get(key) is not None and not embeddings_dict[key].empty
+                      and model_weights.get(key, 0) > 0 and key in q["query_embeddings"]]
+            if len(active) != 1 or (keys is not None and active[0] != keys):
+                return one_by_one()
+            keys = active[0]
+            if params.get("use_reranker", True) and q.get("query_text"):
+                return one_by_one()
+            tokens = q.get("query_tokens")
+            if not tokens and q.get("query_text"):
+                from .preprocess_bm25 import preprocess_text
+
+                tokens = preprocess_text(q["query_text"], use_lemmatization=True)
+            if not tokens:
+                return one_by_one()
+            token_lists.append(tokens)
+        try:
+            emb = np.stack([np.asarray(q["query_embeddings"][keys], dtype=np.float32).reshape(-1) for q in queries])
+            out = self.search_engine.hybrid_search_ids_batch(
+                emb, embeddings_dict[keys], model_weights.get(keys, 1.0), token_lists, bm25, bm25_sections,
+                bm25_section_ids, model_weights.get("BM25", 1.0), similarity_k, common_sections_n,
+                params.get("wrrf_k", 60), params.get("filename_type_filter"))
+        except Exception as e:
+            from ._native import AnragError
+
+            if isinstance(e, AnragError) and e.code in (-100, -5):
+                raise
+            logger.error(f"Batched retrieval failed, answering one by one: {e}")
+            out = None
+        return out if out is not None else one_by_one()
+
     def _section_dict(self, source_enum, bm25_sections):
         # the reference rebuilds this dict over all sections on EVERY query (:192); once is enough
         cache = self.__dict__.setdefault("_section_dicts", {})

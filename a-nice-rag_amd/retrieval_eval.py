@@ -73,6 +73,29 @@ class RetrievalEvaluator:
             return {"rank": -1, "found": False, "total_retrieved": 0, "error": str(e)}
 
 
+    def evaluate_queries(self, items: List[Dict], params: Dict) -> List[Dict]:
+        """`evaluate_query` over a list of {"query", "expected_id", "query_embeddings", "query_tokens"?} items with
+        ONE retrieval call (`retrieve_documents_batch`); element i equals `evaluate_query(**items[i], params=params)`."""
+        try:
+            shared = dict(
+                similarity_k=params["similarity_k"], common_sections_n=params["common_sections_n"],
+                info_source=params.get("info_source", "NICE"), model_weights=params["model_weights"],
+                filename_type_filter=params.get("filename_type_filter"), use_hybrid_search=params["use_hybrid_search"],
+                use_reranker=params.get("use_reranker", False), reranker_model=params.get("reranker_model", "rerank-2"),
+                reranker_top_k=params.get("reranker_top_k"), wrrf_k=params["wrrf_k"])
+            lists = self.retrieval_system.retrieve_documents_batch(
+                [{"query_text": it["query"], "query_embeddings": it["query_embeddings"],
+                  "query_tokens": it.get("query_tokens")} for it in items], **shared)
+        except Exception:
+            return [self.evaluate_query(it["query"], it["expected_id"], it["query_embeddings"], params,
+                                        it.get("query_tokens")) for it in items]
+        out = []
+        for it, docs in zip(items, lists):
+            rank = rank_of(it["expected_id"], docs)
+            out.append({"rank": rank, "found": rank > 0, "total_retrieved": len(docs)})
+        return out
+
+
 def calculate_metrics(results: List[Dict]) -> Dict:
     """retrieval_eval.py:90-116 (a miss counts as rank 100000 for max_rank only)."""
     found = [r for r in results if r.get("found")]

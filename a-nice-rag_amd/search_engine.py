@@ -50,6 +50,21 @@ def bm25_allow(distinct_sources: Sequence[Optional[str]], filename_type_filter: 
                      for s in distinct_sources], dtype=np.uint8)
 
 
+def _allow_of(owner, kind: str, filename_type_filter: str) -> np.ndarray:
+    """Allow list of `owner` (a DenseHandle or Bm25Proxy) for one filter string, evaluated once: the reference
+    re-runs its string tests over every row on every query (search_engine.py:39-48, :227-230); here they run
+    over the DISTINCT sources, and only the first time a filter string is seen."""
+    cache = owner.__dict__.setdefault("_allow_cache", {})
+    key = (kind, filename_type_filter)
+    hit = cache.get(key)
+    if hit is None:
+        if len(cache) >= 256:
+            cache.clear()
+        fn = dense_allow if kind == "dense" else bm25_allow
+        hit = cache[key] = fn(owner.distinct_sources, filename_type_filter)
+    return hit
+
+
 class SearchEngine:
     def __init__(self, voyage_client=None, openai_client=None, encoder=None):
         self.vo = voyage_client
@@ -84,7 +99,7 @@ class SearchEngine:
         """search_engine.py:36-55.  Kept for callers that want the filtered frame; the search methods below
         never materialise it (the filter is an allow-bitmap over interned sources on the device)."""
         h = DenseHandle.of(df)
-        mask = dense_allow(h.distinct_sources, filename_type_filter)[h.source_id].astype(bool)
+        mask = _allow_of(h, "dense", filename_type_filter)[h.source_id].astype(bool)
         filtered = df[mask].copy()
         filtered.attrs.pop(ATTR, None)
         self.logger.info(f"Filtered by filename type(s) '{', '.join(_prefixes(filename_type_filter))}': "
@@ -97,7 +112,7 @@ class SearchEngine:
         h = DenseHandle.of(df)
         allow = None
         if filename_type_filter:
-            allow = dense_allow(h.distinct_sources, filename_type_filter)
+            allow = _allow_of(h, "dense", filename_type_filter)
             if not allow.any():
                 return h, None, None
         q = np.asarray(query_embedding)
@@ -144,7 +159,7 @@ class SearchEngine:
                 return df
             if filename_type_filter:
                 h = DenseHandle.of(df)
-                if not dense_allow(h.distinct_sources, filename_type_filter).any():
+                if not _allow_of(h, "dense", filename_type_filter).any():
                     self.logger.warning(f"No documents found after filtering by filename type: {filename_type_filter}")
                     return df.iloc[0:0]
             if query_embedding is not None:
@@ -171,9 +186,32 @@ class SearchEngine:
         """Many queries in one call (no reference counterpart: SURVEY.md 8a-2; the oracle is a loop of the
         single-query method).  -> (rows [nq, k] int64 (-1 padded), similarities [nq, k] float32)."""
         h = DenseHandle.of(df)
-        allow = dense_allow(h.distinct_sources, filename_type_filter) if filename_type_filter else None
+        allow = _allow_of(h, "dense", filename_type_filter) if filename_type_filter else None
         doc, score, _ = h.index.dense_search(np.asarray(query_embeddings, dtype=np.float32), int(similarity_k), allow)
         return doc, score
+
+    def hybrid_search_ids_batch(self, query_embeddings: np.ndarray, df: pd.DataFrame, dense_weight: float,
+                                query_token_lists: Sequence[List[str]], bm25, bm25_sections, bm25_section_ids,
+                                bm25_weight: float, similarity_k: int, common_sections_n: int, wrrf_k,
+                                filename_type_filter: Optional[str]) -> Optional[List[List[str]]]:
+        """`hybrid_search_ids` for a list of queries in ONE library call (no reference counterpart; element i is
+        what `hybrid_search_ids` returns for query i).  None when outside the fused path's envelope."""
+        if similarity_k > FUSED_K_MAX or common_sections_n > 2 * FUSED_K_MAX:
+            return None
+        if any(not t for t in query_token_lists):
+            return None
+        proxy = self._proxy(bm25, bm25_sections)
+        pair = FusedPair.of(df, proxy, bm25_section_ids)
+        ad = ab = None
+        if filename_type_filter:
+            ad = _allow_of(pair.dense, "dense", filename_type_filter)
+            ab = _allow_of(proxy, "bm25", filename_type_filter)
+        q = np.asarray(query_embeddings, dtype=np.float32).reshape(len(query_token_lists), -1)
+        ids, _, counts = pair.dense.index.hybrid_search_batch(
+            q, [proxy.term_ids(t) for t in query_token_lists], int(similarity_k), float(dense_weight),
+            float(bm25_weight), float(wrrf_k), int(common_sections_n), ad, ab)
+        name = pair.id_of_doc
+        return [[name[i] for i in row[:c].tolist()] for row, c in zip(ids, counts.tolist())]
 
     def _generate_query_embedding(self, query_text: str, model_name: str) -> np.ndarray:
         """search_engine.py:148-159, plus the local-encoder branch the north star adds in place of the
@@ -222,7 +260,7 @@ class SearchEngine:
         if not query_tokens:
             return []
         proxy = self._proxy(bm25, bm25_sections)
-        allow = bm25_allow(proxy.distinct_sources, filename_type_filter) if filename_type_filter else None
+        allow = _allow_of(proxy, "bm25", filename_type_filter) if filename_type_filter else None
         doc, _, count = proxy.index.bm25_search(proxy.term_ids(query_tokens), int(similarity_k), allow)
         return [bm25_section_ids[i] for i in doc[:count].tolist()]
 
@@ -274,8 +312,8 @@ class SearchEngine:
         pair = FusedPair.of(df, proxy, bm25_section_ids)
         ad = ab = None
         if filename_type_filter:
-            ad = dense_allow(pair.dense.distinct_sources, filename_type_filter)
-            ab = bm25_allow(proxy.distinct_sources, filename_type_filter)
+            ad = _allow_of(pair.dense, "dense", filename_type_filter)
+            ab = _allow_of(proxy, "bm25", filename_type_filter)
         ids, _ = pair.dense.index.hybrid_search(q.reshape(-1), proxy.term_ids(query_tokens), int(similarity_k),
                                                 float(dense_weight), float(bm25_weight), float(wrrf_k),
                                                 int(common_sections_n), ad, ab)

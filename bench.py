@@ -55,7 +55,7 @@ def parse_args():
                     help="single-GPU diagnostic: source-prefix filter as retrieval_eval.py:280 passes it ('CG,NG'); rows "
                          "carry one of 300 source ids, 15 %% of them outside the filter (SURVEY.md 8d)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-queries", type=int, default=3, help="queries of the bounded CPU sample")
+    ap.add_argument("--cpu-queries", type=int, default=12, help="queries of the bounded CPU sample")
     return ap.parse_args()
 
 

@@ -228,6 +228,21 @@ int anrag_hybrid_search_device(anrag_index *idx, const float *d_query, const int
                                const uint32_t *d_allow_bm25_bits, anrag_candidate *d_out,
                                int32_t *d_count);
 
+/* n_queries hybrid queries from host memory in ONE call (no reference counterpart: the
+ * reference's retrieval_eval.py:51-84 asks one query at a time; an evaluation run
+ * holds thousands).  queries [n_queries][dim]; query q's term ids are
+ * term_ids[term_offsets[q] .. term_offsets[q+1]) (term_offsets has n_queries+1
+ * entries, term_offsets[0] == 0).  Operands go up once, the queries run back to
+ * back through the stream pipeline of anrag_hybrid_search_device, one host sync.
+ * out_id / out_score [n_queries][top_n] (tail -1 / -inf), out_count [n_queries];
+ * each row equals what anrag_hybrid_search returns for that query. */
+int anrag_hybrid_search_batch(anrag_index *idx, const float *queries, const int32_t *term_ids,
+                              const int64_t *term_offsets, int32_t n_queries,
+                              int32_t similarity_k, double w_dense, double w_bm25, double wrrf_k,
+                              int32_t top_n, const uint8_t *allow_dense, int32_t n_dense_sources,
+                              const uint8_t *allow_bm25, int32_t n_bm25_sources, int64_t *out_id,
+                              double *out_score, int32_t *out_count);
+
 /* ------------------------------------------------------------------ sharded merge
  * After an all-gather of every shard's k candidates: merge n_lists sorted lists of
  * k records each into the global top-k (score desc, doc asc -- row order is

@@ -67,6 +67,15 @@ def test_c1_files_to_recall(tmp_path):
         serial = [ask(i) for i in range(len(data["questions"]))]
         direct = niceqa.gpu_ranked_ids(data)
         assert serial == direct                                   # files + loaders + text tokenisation == direct index
+        # the whole question list in ONE call (anrag_hybrid_search_batch underneath) == the per-query answers
+        shared = dict(similarity_k=25, common_sections_n=10, model_weights=weights, use_hybrid_search=True, wrrf_k=40,
+                      use_reranker=False)
+        batch_in = [{"query_embeddings": {LOCAL_ENCODER_KEY: qv[i]}, "query_text": data["questions"][i][2]}
+                    for i in range(len(data["questions"]))]
+        assert system.retrieve_documents_batch(batch_in, **shared) == serial
+        filtered = [system.retrieve_documents(**q, filename_type_filter="NG", **shared) for q in batch_in]
+        assert system.retrieve_documents_batch(batch_in, filename_type_filter="NG", **shared) == filtered
+        assert filtered != serial
         system.fused = False                                      # method-by-method route (three ABI calls per query)
         assert [ask(i) for i in range(len(data["questions"]))] == serial
         system.fused = True

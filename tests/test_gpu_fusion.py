@@ -94,3 +94,48 @@ def test_hybrid_matches_oracle(idx):
             out_id, _ = h.hybrid_search(q, bi.term_ids(toks), 25, 0.0, 1.0, 40, 15)
             bdoc, _, bcnt = h.bm25_search(bi.term_ids(toks), 25)
             assert out_id.tolist() == bdoc[:15].tolist()
+
+
+def test_hybrid_batch_equals_single_calls():
+    """`anrag_hybrid_search_batch` (one call, device pipeline, > kPipeSlots queries in flight) row by row equals
+    `anrag_hybrid_search`, with and without a source filter, including a query without terms (dense list only)."""
+    from oracle import ref_search
+    from oracle.make_golden import synth_chunks, synth_dense, synth_query
+    from anrag.bm25_index import Bm25Index
+    from anrag.index import Index
+
+    chunks = synth_chunks(900, 91)
+    n, d = len(chunks), 256
+    e = synth_dense(n, d, 92)
+    kept = [i for i, c in enumerate(chunks) if c["tokens"]]
+    bi = Bm25Index([chunks[i]["tokens"] for i in kept], k1=1.7, b=0.83, epsilon=0.05)
+    table = {}
+    sid = np.array([table.setdefault(c["source"], len(table)) for c in chunks], dtype=np.uint16)
+    distinct = list(table)
+    rng = np.random.default_rng(6)
+    nq = 37
+    targets = rng.integers(n, size=nq)
+    qs = np.stack([synth_query(e, 500 + i, int(t)) for i, t in enumerate(targets)])
+    terms = [bi.term_ids([str(t) for t in rng.choice(chunks[int(t)]["tokens"] or ["asthma"], size=int(rng.integers(1, 9)))])
+             for t in targets]
+    terms[5] = np.zeros(0, np.int32)          # no tokens: the dense list alone
+    terms[11] = np.array([-1, -1], np.int32)  # tokens outside the vocabulary: every BM25 score is zero
+    with Index(0) as h:
+        h.dense_load(e, source_id=sid)
+        h.bm25_load(bi.indptr, bi.post_doc, bi.post_tf, bi.idf, bi.doc_len, bi.avgdl, bi.k1, bi.b,
+                    source_id=sid[kept], doc_id=np.array(kept, dtype=np.int64))
+        for sim_k, top_n, flt in ((25, 10, None), (25, 15, "CG,NG"), (64, 12, "NG")):
+            ad = None if flt is None else ref_search.dense_filter_mask(distinct, flt).astype(np.uint8)
+            ab = None if flt is None else ref_search.bm25_filter_mask(distinct, flt).astype(np.uint8)
+            ids, scores, counts = h.hybrid_search_batch(qs, terms, sim_k, 5.0, 1.0, 40.0, top_n, ad, ab)
+            assert ids.shape == (nq, top_n)
+            for i in range(nq):
+                want_id, want_score = h.hybrid_search(qs[i], terms[i], sim_k, 5.0, 1.0, 40.0, top_n, ad, ab)
+                c = int(counts[i])
+                assert c == len(want_id)
+                assert ids[i, :c].tolist() == want_id.tolist(), (i, flt)
+                assert scores[i, :c].tolist() == want_score.tolist()
+                assert (ids[i, c:] == -1).all()
+        # an empty batch is a no-op
+        ids, _, counts = h.hybrid_search_batch(np.zeros((0, d), np.float32), [], 25, 5.0, 1.0, 40.0, 10)
+        assert ids.shape == (0, 10) and counts.shape == (0,)
