@@ -129,3 +129,102 @@ def append_results_csv(path: str, model_label: str, metrics: Dict) -> None:
             w.writerow(CSV_HEADER)
         w.writerow([model_label, metrics["mrr"], metrics["recall@1"], metrics["recall@5"], metrics["recall@10"],
                     metrics["recall@15"], metrics["median_rank"], metrics["mean_rank"], metrics["max_rank"]])
+
+
+# ---------------------------------------------------------------------------------------------------
+# The evaluation run (reference: retrieval_eval.py:121-420, a script with its paths and nine configurations
+# written into `main`).  Same selection rules, same split, same CSV rows; the queries of a configuration go to
+# the retrieval system as lists (`evaluate_queries`), not one call each.
+DENSE_KEYS = ("voyage-3-large", "voyage-3.5", "text-embedding-3-large", "Qwen3")
+
+
+def _configuration(name, weights, hybrid, k=12000, n=12000, **extra):
+    w = {key: 0.0 for key in DENSE_KEYS}
+    w["BM25"] = 0.0
+    w.update(weights)
+    return dict(name=name, model_weights=w, use_hybrid_search=hybrid, similarity_k=k, common_sections_n=n, **extra)
+
+
+# retrieval_eval.py:130-268 as a table: (label, non-zero weights, hybrid?, k, n, reranker)
+REFERENCE_CONFIGURATIONS = [
+    _configuration("Voyage-3-Large", {"voyage-3-large": 1.0}, False),
+    _configuration("Voyage-3.5", {"voyage-3.5": 1.0}, False),
+    _configuration("Text-Embedding-3-Large", {"text-embedding-3-large": 1.0}, False),
+    _configuration("Qwen3-Embedding-0.6B", {"Qwen3": 1.0}, False),
+    _configuration("BM25", {"BM25": 1.0}, True),
+    _configuration("Voyage-3-Large + BM25", {"voyage-3-large": 5.0, "BM25": 1.0}, True),
+    _configuration("Voyage-3-Large + Text-Embedding-3-Large", {"voyage-3-large": 2.0, "text-embedding-3-large": 1.0}, False),
+    _configuration("Voyage-3-Large + BM25 (Reranker 2 Lite)", {"voyage-3-large": 5.0, "BM25": 1.0}, True, 25, 15,
+                   use_reranker=True, reranker_model="rerank-2-lite", reranker_top_k=10),
+    _configuration("Voyage-3-Large + BM25 (Reranker 2)", {"voyage-3-large": 5.0, "BM25": 1.0}, True, 25, 15,
+                   use_reranker=True, reranker_model="rerank-2", reranker_top_k=10),
+]
+BASE_PARAMS = {"wrrf_k": 40, "filename_type_filter": "CG,NG"}  # retrieval_eval.py:278-281
+
+
+def select_queries(cached_dbs: Dict[str, pd.DataFrame], model_weights: Dict[str, float],
+                   reference_model: str = "voyage-3-large"):
+    """retrieval_eval.py:309-336: the query table of the heaviest active dense model (the reference model's for a
+    BM25-only run), inner-joined on query id with every other active model's embeddings."""
+    active = [k for k in model_weights if k != "BM25" and model_weights.get(k, 0) > 0]
+    main = max(active, key=lambda k: model_weights[k]) if active else reference_model
+    queries = cached_dbs[main].copy()
+    embeddings = {main: queries["query_embedding"].values}
+    for model in active:
+        if model == main:
+            continue
+        merged = queries.merge(cached_dbs[model][["id", "query_embedding"]], on="id", how="left",
+                               suffixes=("", f"_{model}"))
+        col = f"query_embedding_{model}"
+        embeddings[model] = merged[col].values
+        queries = merged[merged[col].notna()].copy()
+    return queries, embeddings
+
+
+def format_csv_row(name: str, m: Dict) -> str:
+    """retrieval_eval.py:401-417: three decimals, 'N/A' for the ranks of an all-miss run."""
+    mean = f"{m['mean_rank']:.3f}" if m["mean_rank"] is not None else "N/A"
+    median = str(m["median_rank"]) if m["median_rank"] is not None else "N/A"
+    return (f"{name},{m['mrr']:.3f},{m['recall@1']:.3f},{m['recall@5']:.3f},{m['recall@10']:.3f},"
+            f"{m['recall@15']:.3f},{median},{mean},{m['max_rank']}\n")
+
+
+def run_evaluation(evaluator: RetrievalEvaluator, cached_dbs: Dict[str, pd.DataFrame], preprocessed: pd.DataFrame,
+                   output_file: str, configurations: Optional[List[Dict]] = None, base_params: Optional[Dict] = None,
+                   reference_model: str = "voyage-3-large", chunk: int = 2048) -> List[Dict]:
+    """retrieval_eval.py:270-420.  -> one metrics dict per configuration, each also appended to `output_file`."""
+    from sklearn.model_selection import train_test_split
+
+    configurations = REFERENCE_CONFIGURATIONS if configurations is None else configurations
+    base_params = BASE_PARAMS if base_params is None else base_params
+    # :273-276 -- the split is drawn once over the reference model's table; the 85 % side is what gets evaluated
+    train_idx, _ = train_test_split(range(len(cached_dbs[reference_model])), test_size=0.15, random_state=42,
+                                    shuffle=True)
+    train_idx = np.asarray(train_idx)
+    os.makedirs(os.path.dirname(output_file) or ".", exist_ok=True)
+    if not os.path.exists(output_file):
+        with open(output_file, "w") as f:
+            f.write(",".join(CSV_HEADER) + "\n")
+    tokens_of = dict(zip(preprocessed["id"], preprocessed["tokens_lemmatized"]))
+    all_metrics = []
+    for config in configurations:
+        weights = config["model_weights"]
+        queries, embeddings = select_queries(cached_dbs, weights, reference_model)
+        test_queries = queries.iloc[train_idx].reset_index(drop=True)
+        test_embeddings = {k: v[train_idx] for k, v in embeddings.items()}
+        need_tokens = weights.get("BM25", 0) > 0 and config["use_hybrid_search"]
+        params = dict(base_params)
+        params.update({k: v for k, v in config.items() if k != "name"})
+        items = []
+        for i, row in enumerate(test_queries.itertuples(index=False)):
+            qe = {k: v[i] for k, v in test_embeddings.items() if i < len(v) and v[i] is not None}
+            items.append({"query": row.query, "expected_id": row.id, "query_embeddings": qe,
+                          "query_tokens": tokens_of.get(row.id) if need_tokens else None})
+        results: List[Dict] = []
+        for lo in range(0, len(items), chunk):
+            results.extend(evaluator.evaluate_queries(items[lo: lo + chunk], params))
+        metrics = calculate_metrics(results)
+        with open(output_file, "a") as f:
+            f.write(format_csv_row(config["name"], metrics))
+        all_metrics.append(metrics)
+    return all_metrics

@@ -157,3 +157,67 @@ def test_evaluator_and_metrics(world):
     for c in load_golden("ref_metrics.json"):
         got = {k: (None if v is None else float(v)) for k, v in calculate_metrics(c["results"]).items()}
         assert got == c["metrics"]
+
+
+def test_evaluation_run_lists_equal_single_queries(world, tmp_path):
+    """The evaluation run (reference retrieval_eval.py:270-420: configuration table, query selection, 85 % split,
+    CSV rows) asks its queries as LISTS; every configuration's metrics must equal those of the per-query
+    `evaluate_query` loop -- full-ranking configurations (k = 12000, radix-sort path), BM25 only, the fused
+    hybrid route and a two-model fusion."""
+    import sqlite3
+
+    from oracle.make_golden import synth_query
+    from anrag.query_rag_retrieval import RetrievalEvaluationSystem
+    from anrag import retrieval_eval as re_
+
+    g, cfg, e1, e2, kept = world
+    chunks = g["corpus"]["chunks"]
+    targets = [i for i in range(len(chunks)) if chunks[i]["tokens"]][:120]
+
+    def write_queries(path, emb, seed0, skip=()):
+        conn = sqlite3.connect(path)
+        conn.execute("CREATE TABLE queries (id TEXT PRIMARY KEY, query TEXT, query_embedding BLOB)")
+        for j, t in enumerate(targets):
+            if j in skip:
+                continue
+            conn.execute("INSERT INTO queries VALUES (?,?,?)",
+                         (chunks[t]["id"], "q about " + " ".join(chunks[t]["tokens"][:3]),
+                          synth_query(emb, seed0 + j, t).astype(np.float32).tobytes()))
+        conn.commit()
+        conn.close()
+
+    p1, p2 = str(tmp_path / "q1.db"), str(tmp_path / "q2.db")
+    write_queries(p1, e1, 7000)
+    write_queries(p2, e2, 8000)
+    cached = {"voyage-3-large": re_.load_queries_from_db(p1), "text-embedding-3-large": re_.load_queries_from_db(p2)}
+    pre = pd.DataFrame({"id": [chunks[t]["id"] for t in targets],
+                        "tokens_lemmatized": [chunks[t]["tokens"][:4] for t in targets]})
+    configs = [
+        re_._configuration("dense full ranking", {"voyage-3-large": 1.0}, False),
+        re_._configuration("bm25 full ranking", {"BM25": 1.0}, True),
+        re_._configuration("hybrid fused", {"voyage-3-large": 5.0, "BM25": 1.0}, True, 25, 15),
+        re_._configuration("two models", {"voyage-3-large": 2.0, "text-embedding-3-large": 1.0}, False, 25, 15),
+    ]
+    ev = re_.RetrievalEvaluator(retrieval_system=RetrievalEvaluationSystem(cfg))
+    out_csv = str(tmp_path / "results" / "eval.csv")
+    metrics = re_.run_evaluation(ev, cached, pre, out_csv, configs, chunk=50)
+    lines = open(out_csv).read().splitlines()
+    assert lines[0] == ",".join(re_.CSV_HEADER) and len(lines) == 1 + len(configs)
+
+    from sklearn.model_selection import train_test_split
+    train_idx, _ = train_test_split(range(len(targets)), test_size=0.15, random_state=42, shuffle=True)
+    tokens_of = dict(zip(pre["id"], pre["tokens_lemmatized"]))
+    for config, m, line in zip(configs, metrics, lines[1:]):
+        params = dict(re_.BASE_PARAMS)
+        params.update({k: v for k, v in config.items() if k != "name"})
+        queries, embeddings = re_.select_queries(cached, config["model_weights"])
+        need = config["model_weights"]["BM25"] > 0 and config["use_hybrid_search"]
+        single = []
+        for i in train_idx:
+            row = queries.iloc[i]
+            single.append(ev.evaluate_query(row["query"], row["id"], {k: v[i] for k, v in embeddings.items()}, params,
+                                            tokens_of.get(row["id"]) if need else None))
+        want = re_.calculate_metrics(single)
+        assert m == want, config["name"]
+        assert m["total"] == len(train_idx) and m["recall@10"] > 0.5, (config["name"], m)
+        assert line == re_.format_csv_row(config["name"], want).rstrip("\n")
