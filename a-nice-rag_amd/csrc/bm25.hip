@@ -73,6 +73,15 @@ __global__ void bm25_part_ptr_kernel(const int64_t *__restrict__ indptr, const i
 }
 
 // ------------------------------------------------------------------ query kernel
+// LDS plan of one workgroup (dynamic, ~100 KB: one workgroup per CU, which is what one partition per CU wants):
+//   slice[4096] fp64 scores | staged postings: st_val[kStageCap] fp64 + st_doc[kStageCap] u16 (the selection's
+//   merge lists reuse the staging area afterwards) | term table | allow bitmap
+constexpr int kStageCap = 6144;                    // staged postings per gather round
+constexpr int kStagePerThread = kStageCap / kBm25Threads;
+constexpr uint16_t kNoDoc = 0xFFFF;                // staged posting outside this partition (rare-term scan)
+constexpr int kBm25LdsBytes = kMaxPartDocs * 8 + kStageCap * 8 + kStageCap * 2 + kTermBatch * (8 + 8 + 4 + 4) + 2048 * 4;
+static_assert(kBm25Waves * kListLen * (8 + 4) <= kStageCap * 8, "merge lists must fit in the staging area");
+
 template <bool FILTER, bool SCORES>
 __global__ __launch_bounds__(kBm25Threads) void bm25_kernel(
     const int64_t *__restrict__ indptr, const int32_t *__restrict__ post_doc, const double *__restrict__ impact,
@@ -80,13 +89,17 @@ __global__ __launch_bounds__(kBm25Threads) void bm25_kernel(
     int32_t n_parts, int32_t part_docs, int64_t n_docs, int64_t n_vocab, const int32_t *__restrict__ terms,
     int32_t n_terms, int32_t k, const uint16_t *__restrict__ src, const uint32_t *__restrict__ allow_bits,
     double *__restrict__ blk_score, uint32_t *__restrict__ blk_row, double *__restrict__ scores_out) {
-    __shared__ double slice[kMaxPartDocs];
-    __shared__ double t_w[kTermBatch];
-    __shared__ int64_t t_base[kTermBatch];
-    __shared__ int32_t t_begin[kTermBatch], t_end[kTermBatch];
-    __shared__ double lds_s[kBm25Waves * kListLen];
-    __shared__ uint32_t lds_r[kBm25Waves * kListLen];
-    __shared__ uint32_t lds_allow[FILTER ? 2048 : 1];
+    extern __shared__ __attribute__((aligned(16))) unsigned char bm25_lds[];
+    double *slice = reinterpret_cast<double *>(bm25_lds);
+    double *st_val = slice + kMaxPartDocs;
+    uint16_t *st_doc = reinterpret_cast<uint16_t *>(st_val + kStageCap);
+    double *t_w = reinterpret_cast<double *>(st_doc + kStageCap);
+    int64_t *t_base = reinterpret_cast<int64_t *>(t_w + kTermBatch);
+    int32_t *t_begin = reinterpret_cast<int32_t *>(t_base + kTermBatch);
+    int32_t *t_cnt = t_begin + kTermBatch;
+    uint32_t *lds_allow = reinterpret_cast<uint32_t *>(t_cnt + kTermBatch);
+    double *lds_s = st_val;                                              // after the last term
+    uint32_t *lds_r = reinterpret_cast<uint32_t *>(st_val + kBm25Waves * kListLen);
 
     const int tid = threadIdx.x;
     const int32_t part = blockIdx.x;
@@ -98,24 +111,12 @@ __global__ __launch_bounds__(kBm25Threads) void bm25_kernel(
     if constexpr (FILTER)
         for (int i = tid; i < 2048; i += kBm25Threads) lds_allow[i] = allow_bits[i];
 
-    // One term = at most kPostPerThread postings per thread (a partition holds <= 4096 documents and a term
-    // names a document once).  The postings of term j+1 are fetched into registers BEFORE the barrier that
-    // closes term j, so the dependent HBM round trips of consecutive terms overlap.
-    struct Fetched {
-        int32_t d[kPostPerThread];
-        double v[kPostPerThread];
-    };
-    auto fetch = [&](int32_t j, Fetched &f) {
-        const int64_t base = t_base[j];
-        const int32_t a = t_begin[j], e = t_end[j];
-#pragma unroll
-        for (int u = 0; u < kPostPerThread; ++u) {
-            const int32_t i = a + tid + u * kBm25Threads;
-            const bool in = i < e;
-            f.d[u] = in ? post_doc[base + i] : -1;
-            f.v[u] = in ? impact[base + i] : 0.0;
-        }
-    };
+    // Term-at-a-time, but the HBM round trips are not: the postings of as many consecutive query terms as fit the
+    // staging area are GATHERED in one round (every load of the round is independent and in flight together),
+    // then APPLIED to the score slice term by term in query order, out of LDS, with a barrier between terms --
+    // two postings of one term never name the same document, postings of different terms stay ordered, so every
+    // fp64 sum is formed in exactly the reference's order.  (Walking the terms with one dependent HBM round trip
+    // each, the next one prefetched, took 34 us for 9 terms at 1M documents: 12 round trips, 6.7 % of HBM.)
     for (int32_t b0 = 0; b0 < n_terms; b0 += kTermBatch) {
         const int32_t nb = n_terms - b0 < kTermBatch ? n_terms - b0 : kTermBatch;
         __syncthreads();  // slice zeroed / previous batch's table no longer read
@@ -132,28 +133,67 @@ __global__ __launch_bounds__(kBm25Threads) void bm25_kernel(
                     a = part_ptr[(int64_t)slot * (n_parts + 1) + part];
                     e = part_ptr[(int64_t)slot * (n_parts + 1) + part + 1];
                 } else {
-                    e = (int32_t)(indptr[t + 1] - base);  // < kFrequentDf: scanned whole
+                    e = (int32_t)(indptr[t + 1] - base);  // < kFrequentDf: scanned whole, range-checked
                 }
                 if (w == 0.0) e = a;
             }
             t_w[tid] = w;
             t_base[tid] = base;
             t_begin[tid] = a;
-            t_end[tid] = e;
+            t_cnt[tid] = e - a;  // <= part_docs (one posting per document and term) or < kFrequentDf
         }
         __syncthreads();
-        Fetched cur, nxt;
-        fetch(0, cur);
-        for (int32_t j = 0; j < nb; ++j) {
-            if (j + 1 < nb) fetch(j + 1, nxt);
-            const double w = t_w[j];
+        int32_t j0 = 0;
+        while (j0 < nb) {
+            // the round's terms [j0, j1): greedy, at least one (a term alone always fits)
+            int32_t j1 = j0, total = 0;
+            while (j1 < nb && total + t_cnt[j1] <= kStageCap) total += t_cnt[j1++];
+            // gather: staged entry f <- posting (term, i); a thread's entries are f = tid + u * 1024.  Three
+            // separate passes -- addresses, loads, stores -- so that no use of a loaded value (and no branch) sits
+            // between two loads: all of a thread's loads are in flight together, one round trip per gather.
+            int64_t g_at[kStagePerThread];
+            {
+                int32_t j = j0, off = 0;  // term of the current entry and its first staged index
 #pragma unroll
-            for (int u = 0; u < kPostPerThread; ++u) {
-                const int64_t d = cur.d[u];
-                if (d >= lo && d < hi) slice[d - lo] = slice[d - lo] + w * cur.v[u];
+                for (int u = 0; u < kStagePerThread; ++u) {
+                    const int32_t f = tid + u * kBm25Threads;
+                    g_at[u] = 0;  // lanes past the end re-read posting 0 (one cache line, always there)
+                    if (f < total) {
+                        while (f >= off + t_cnt[j]) off += t_cnt[j++];
+                        g_at[u] = t_base[j] + t_begin[j] + (f - off);
+                    }
+                }
             }
-            __syncthreads();  // term j is complete before term j+1 may touch the same document
-            cur = nxt;
+            int32_t g_doc[kStagePerThread];
+            double g_val[kStagePerThread];
+#pragma unroll
+            for (int u = 0; u < kStagePerThread; ++u) {
+                g_doc[u] = post_doc[g_at[u]];
+                g_val[u] = impact[g_at[u]];
+            }
+#pragma unroll
+            for (int u = 0; u < kStagePerThread; ++u) {
+                const int32_t f = tid + u * kBm25Threads;
+                if (f < total) {
+                    const int64_t d = g_doc[u];
+                    st_doc[f] = (d >= lo && d < hi) ? (uint16_t)(d - lo) : kNoDoc;
+                    st_val[f] = g_val[u];
+                }
+            }
+            __syncthreads();
+            // apply, in query order
+            int32_t off = 0;
+            for (int32_t j = j0; j < j1; ++j) {
+                const double w = t_w[j];
+                const int32_t cnt = t_cnt[j];
+                for (int32_t i = tid; i < cnt; i += kBm25Threads) {
+                    const uint16_t d = st_doc[off + i];
+                    if (d != kNoDoc) slice[d] = slice[d] + w * st_val[off + i];
+                }
+                off += cnt;
+                __syncthreads();  // term j is complete before term j+1 may touch the same document
+            }
+            j0 = j1;
         }
     }
     if (n_terms == 0) __syncthreads();
@@ -165,18 +205,44 @@ __global__ __launch_bounds__(kBm25Threads) void bm25_kernel(
             scores_out[lo + i] = ok ? slice[i] : neg_inf<double>();
         }
     } else {
+        // Selection over the LDS slice.  The sorting networks are what this costs, so they run as rarely as
+        // possible: a thread holds part_docs / 1024 <= 4 documents, and its BEST one is offered first -- 64
+        // candidates, one sort -- which makes the wave's k-th best so far a bound most of the remaining documents
+        // fail, so the other three rounds are a ballot and a few wave-uniform insertions (offering 64 documents per
+        // round in index order took ~4 sorts per wave).  Then the usual tree merge of the 16 wave lists.
         WaveTopK<double> top;
         top.init(k);
-        for (int i0 = 0; i0 < len; i0 += kBm25Threads) {
-            const int i = i0 + tid;
-            bool ok = i < len;
-            double s = neg_inf<double>();
-            if (ok) {
-                s = slice[i];
-                if constexpr (FILTER) ok = source_ok(lds_allow, src[lo + i]);
+        double sc[kPostPerThread];
+        bool okk[kPostPerThread];
+        int bu = 0;
+#pragma unroll
+        for (int u = 0; u < kPostPerThread; ++u) {
+            const int i = tid + u * kBm25Threads;
+            okk[u] = i < len;
+            sc[u] = neg_inf<double>();
+            if (okk[u]) {
+                sc[u] = slice[i];
+                if constexpr (FILTER) okk[u] = source_ok(lds_allow, src[lo + i]);
             }
-            const uint32_t r = (uint32_t)(lo + i);
-            top.offer_lanes(ok && top.admits(s, r), s, r);
+            // rows ascend with u: a strict > keeps the lower row among equal scores
+            if (u > 0 && okk[u] && (!okk[bu] || sc[u] > sc[bu])) bu = u;
+        }
+        {
+            double bs = sc[0];
+            bool bo = okk[0];
+#pragma unroll
+            for (int u = 1; u < kPostPerThread; ++u)
+                if (bu == u) {
+                    bs = sc[u];
+                    bo = okk[u];
+                }
+            const uint32_t br = (uint32_t)(lo + tid + bu * kBm25Threads);
+            top.offer_lanes(bo && top.admits(bs, br), bs, br);
+        }
+#pragma unroll
+        for (int u = 0; u < kPostPerThread; ++u) {
+            const uint32_t r = (uint32_t)(lo + tid + u * kBm25Threads);
+            top.offer_lanes(okk[u] && u != bu && top.admits(sc[u], r), sc[u], r);
         }
         block_merge(top, lds_s, lds_r, kBm25Waves);
         if (threadIdx.x < kWave) {
@@ -341,12 +407,24 @@ int bm25_load(anrag_index *idx, const int64_t *indptr, int64_t n_terms, const in
 int launch_bm25_lists(anrag_index *idx, hipStream_t st, const int32_t *d_terms, int32_t n_terms, int32_t k,
                       const uint32_t *d_allow_bits, double *d_scores_out, int set) {
     const uint32_t *allow = idx->d_bm25_src ? d_allow_bits : nullptr;
+    static bool attr_set = false;
+    if (!attr_set) {  // ~100 KB of LDS per workgroup: above the 64 KB a kernel gets without asking
+#define ANRAG_BM25_ATTR(F, S)                                                                         \
+    ANRAG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&bm25_kernel<F, S>),                 \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, kBm25LdsBytes))
+        ANRAG_BM25_ATTR(false, false);
+        ANRAG_BM25_ATTR(false, true);
+        ANRAG_BM25_ATTR(true, false);
+        ANRAG_BM25_ATTR(true, true);
+#undef ANRAG_BM25_ATTR
+        attr_set = true;
+    }
     double *blk_s = idx->d_blk_score_f64 + (int64_t)set * idx->n_parts * kListLen;
     uint32_t *blk_r = idx->d_blk_row_b + (int64_t)set * idx->n_parts * kListLen;
     {
         LaunchTimer t(idx, ANRAG_KERNEL_BM25, st);
 #define ANRAG_BM25(F, S)                                                                                          \
-    bm25_kernel<F, S><<<idx->n_parts, kBm25Threads, 0, st>>>(                                                      \
+    bm25_kernel<F, S><<<idx->n_parts, kBm25Threads, kBm25LdsBytes, st>>>(                                          \
         idx->d_indptr, idx->d_post_doc, idx->d_post_impact, idx->d_idf, idx->d_part_slot, idx->d_part_ptr,        \
         idx->n_parts, idx->part_docs, idx->n_docs, idx->n_terms, d_terms, n_terms, k, idx->d_bm25_src, allow,     \
         blk_s, blk_r, d_scores_out)

@@ -1,7 +1,7 @@
 // K4 -- selection over candidate lists.
 //
-//  * the per-workgroup lists K1 / K3 produce are merged INSIDE those kernels by their last workgroup
-//    (wave_topk.hpp, publish_and_merge_lists); what is left here is the cross-shard merge:
+//  * the per-workgroup lists K1 / K3 produce are merged by the tail kernel (tail.hip); what is left here is the
+//    cross-shard merge:
 //  * merge_candidates_kernel: n_lists sorted lists of k anrag_candidate records (the RCCL
 //    all-gather receive buffer of the sharded path) -> global top-k by
 //    (score desc, doc asc).  Replicated on every rank, latency-bound, one wavefront.
@@ -36,16 +36,16 @@ struct DocTopK {
     __device__ __forceinline__ void insert(double cs, long long cd) {
         const int lane = threadIdx.x & 63;
         const bool ahead = beats(s, d, cs, cd);
-        const double up_s = __shfl_up(s, 1);
-        const long long up_d = __shfl_up(d, 1);
-        const int up_ahead = __shfl_up((int)ahead, 1);
+        const double up_s = lane_up1(s);
+        const long long up_d = __double_as_longlong(lane_up1(__longlong_as_double(d)));  // bits only
+        const uint32_t up_ahead = lane_up1((uint32_t)ahead);
         if (!ahead) {
             const bool first = (lane == 0) || up_ahead;
             s = first ? cs : up_s;
             d = first ? cd : up_d;
         }
-        thr_s = __shfl(s, k - 1);
-        thr_d = __shfl(d, k - 1);
+        thr_s = read_lane(s, k - 1);
+        thr_d = __double_as_longlong(read_lane(__longlong_as_double(d), k - 1));
     }
 };
 
@@ -62,8 +62,8 @@ __global__ __launch_bounds__(64) void merge_candidates_kernel(const anrag_candid
         c.doc = -1;
         if (lane < k) c = lists[(int64_t)li * stride + lane];
         for (int i = 0; i < k; ++i) {
-            const double cs = __shfl(c.score, i);
-            const long long cd = __shfl((long long)c.doc, i);
+            const double cs = read_lane(c.score, i);
+            const long long cd = __double_as_longlong(read_lane(__longlong_as_double((long long)c.doc), i));
             if (!top.admits(cs, cd)) break;
             top.insert(cs, cd);
         }
@@ -101,8 +101,8 @@ __global__ __launch_bounds__(128) void merge_fuse_kernel(const anrag_candidate *
         c.doc = -1;
         if (lane < k) c = lists[(int64_t)li * stride + wave * k + lane];
         for (int i = 0; i < k; ++i) {
-            const double cs = __shfl(c.score, i);
-            const long long cd = __shfl((long long)c.doc, i);
+            const double cs = read_lane(c.score, i);
+            const long long cd = __double_as_longlong(read_lane(__longlong_as_double((long long)c.doc), i));
             if (!top.admits(cs, cd)) break;
             top.insert(cs, cd);
         }

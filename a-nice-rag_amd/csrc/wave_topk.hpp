@@ -45,12 +45,67 @@ __device__ __forceinline__ double read_lane(double v, int l) {
     return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
 
+// ---- lane exchanges without LDS.  A ds_bpermute round trip is ~250 cycles and a sorting network is a chain of
+// them (one 27-stage sort+merge of fp64 keys measured 2-3 us); these are VALU moves of a few cycles each:
+//   lane ^ 1, ^ 2      DPP quad_perm                                   lane ^ 16   v_permlane16_swap (gfx950)
+//   lane ^ 4           DPP row_half_mirror, then quad_perm [3,2,1,0]    lane ^ 32   v_permlane32_swap (gfx950)
+//   lane ^ 8           DPP row_mirror, then row_half_mirror
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_move(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, false);
+}
+template <int STRIDE>
+__device__ __forceinline__ uint32_t lane_xor(uint32_t v) {
+    static_assert(STRIDE == 1 || STRIDE == 2 || STRIDE == 4 || STRIDE == 8 || STRIDE == 16 || STRIDE == 32, "");
+    if constexpr (STRIDE == 1) return dpp_move<0xB1>(v);
+    else if constexpr (STRIDE == 2) return dpp_move<0x4E>(v);
+    else if constexpr (STRIDE == 4) return dpp_move<0x1B>(dpp_move<0x141>(v));
+    else if constexpr (STRIDE == 8) return dpp_move<0x141>(dpp_move<0x140>(v));
+    else if constexpr (STRIDE == 16) {
+        // odd rows of the first copy <-> even rows of the second: {r0,r0,r2,r2} and {r1,r1,r3,r3}
+        const auto p = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+        return (threadIdx.x & 16) ? p[0] : p[1];
+    } else {
+        // upper half of the first copy <-> lower half of the second: {lo,lo} and {hi,hi}
+        const auto p = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+        return (threadIdx.x & 32) ? p[0] : p[1];
+    }
+}
+template <int STRIDE>
+__device__ __forceinline__ float lane_xor(float v) {
+    return __uint_as_float(lane_xor<STRIDE>(__float_as_uint(v)));
+}
+template <int STRIDE>
+__device__ __forceinline__ double lane_xor(double v) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    const uint32_t lo = lane_xor<STRIDE>((uint32_t)b), hi = lane_xor<STRIDE>((uint32_t)(b >> 32));
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+// lane -> 63 - lane (= lane ^ 63): mirror inside the rows of 16, then swap rows and halves
+__device__ __forceinline__ uint32_t lane_reverse(uint32_t v) { return lane_xor<32>(lane_xor<16>(dpp_move<0x140>(v))); }
+__device__ __forceinline__ float lane_reverse(float v) { return __uint_as_float(lane_reverse(__float_as_uint(v))); }
+__device__ __forceinline__ double lane_reverse(double v) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    const uint32_t lo = lane_reverse((uint32_t)b), hi = lane_reverse((uint32_t)(b >> 32));
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+// value of lane - 1 (lane 0 keeps its own): DPP wave_shr:1
+__device__ __forceinline__ uint32_t lane_up1(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x138, 0xF, 0xF, false);
+}
+__device__ __forceinline__ float lane_up1(float v) { return __uint_as_float(lane_up1(__float_as_uint(v))); }
+__device__ __forceinline__ double lane_up1(double v) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    const uint32_t lo = lane_up1((uint32_t)b), hi = lane_up1((uint32_t)(b >> 32));
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
 // ---- sorting networks over the 64 lanes (one (score,row) pair per lane, best first)
-// compare-exchange with lane ^ stride: keep the better of the pair when `keep_better`, else the worse
-template <typename S>
-__device__ __forceinline__ void cmp_exchange(S &s, uint32_t &r, int stride, bool keep_better) {
-    const S os = __shfl_xor(s, stride);
-    const uint32_t orow = __shfl_xor(r, stride);
+// compare-exchange with lane ^ STRIDE: keep the better of the pair when `keep_better`, else the worse
+template <int STRIDE, typename S>
+__device__ __forceinline__ void cmp_exchange(S &s, uint32_t &r, bool keep_better) {
+    const S os = lane_xor<STRIDE>(s);
+    const uint32_t orow = lane_xor<STRIDE>(r);
     const bool other_better = beats(os, orow, s, r);
     if (other_better == keep_better) {
         s = os;
@@ -58,28 +113,32 @@ __device__ __forceinline__ void cmp_exchange(S &s, uint32_t &r, int stride, bool
     }
 }
 
+template <int SIZE, int STRIDE, typename S>
+__device__ __forceinline__ void bitonic_sort_from(S &s, uint32_t &r, int lane) {
+    if constexpr (SIZE <= kWave) {
+        const bool lower = (lane & STRIDE) == 0;
+        const bool desc = (lane & SIZE) == 0 || SIZE == kWave;
+        cmp_exchange<STRIDE>(s, r, lower == desc);
+        if constexpr (STRIDE > 1) bitonic_sort_from<SIZE, STRIDE / 2>(s, r, lane);
+        else bitonic_sort_from<SIZE * 2, SIZE>(s, r, lane);
+    }
+}
 // full bitonic sort, descending by (score desc, row asc): 21 compare-exchange stages
 template <typename S>
 __device__ __forceinline__ void bitonic_sort64(S &s, uint32_t &r) {
-    const int lane = threadIdx.x & (kWave - 1);
-#pragma unroll
-    for (int size = 2; size <= kWave; size <<= 1) {
-#pragma unroll
-        for (int stride = size >> 1; stride >= 1; stride >>= 1) {
-            const bool lower = (lane & stride) == 0;
-            const bool desc = (lane & size) == 0 || size == kWave;
-            cmp_exchange(s, r, stride, lower == desc);
-        }
-    }
+    bitonic_sort_from<2, 1>(s, r, threadIdx.x & (kWave - 1));
 }
 
+template <int STRIDE, typename S>
+__device__ __forceinline__ void bitonic_merge_from(S &s, uint32_t &r, int lane) {
+    cmp_exchange<STRIDE>(s, r, (lane & STRIDE) == 0);
+    if constexpr (STRIDE > 1) bitonic_merge_from<STRIDE / 2>(s, r, lane);
+}
 // (s, r) holds a bitonic sequence (first descending, then ascending, or any rotation-free bitonic
 // shape produced by the max-with-reversed trick below): 6 stages sort it descending
 template <typename S>
 __device__ __forceinline__ void bitonic_merge64(S &s, uint32_t &r) {
-    const int lane = threadIdx.x & (kWave - 1);
-#pragma unroll
-    for (int stride = kWave >> 1; stride >= 1; stride >>= 1) cmp_exchange(s, r, stride, (lane & stride) == 0);
+    bitonic_merge_from<kWave / 2>(s, r, threadIdx.x & (kWave - 1));
 }
 
 template <typename S>
@@ -103,9 +162,9 @@ struct WaveTopK {
     __device__ __forceinline__ void insert(S cs, uint32_t cr) {
         const int lane = lane_id();
         const bool ahead = beats(s, r, cs, cr);  // this slot outranks the newcomer
-        const S up_s = __shfl_up(s, 1);
-        const uint32_t up_r = __shfl_up(r, 1);
-        const int up_ahead = __shfl_up((int)ahead, 1);
+        const S up_s = lane_up1(s);
+        const uint32_t up_r = lane_up1(r);
+        const uint32_t up_ahead = lane_up1((uint32_t)ahead);
         if (!ahead) {
             const bool first = (lane == 0) || up_ahead;
             s = first ? cs : up_s;
@@ -146,8 +205,7 @@ struct WaveTopK {
         S ss = flag ? cs : neg_inf<S>();
         uint32_t sr = flag ? cr : kNoRow;
         bitonic_sort64(ss, sr);
-        const int rev = kWave - 1 - lane_id();
-        merge_reversed(__shfl(ss, rev), __shfl(sr, rev));
+        merge_reversed(lane_reverse(ss), lane_reverse(sr));
     }
 
     // Merge a sorted 64-entry list that lives in LDS (lane i reads entry 63-i: the reversal is free).

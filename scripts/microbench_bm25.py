@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""K3 alone: BM25 queries over synthetic postings of bench.py's shape, operands resident in HBM.
+Reports the kernel's mean duration against its algorithmic bytes (SURVEY.md 8d restated for this layout:
+sum over the query's terms of df(t) * 12 B -- a posting is an int32 doc id + an fp64 impact).
+usage: python scripts/microbench_bm25.py [n_docs] [iters]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from anrag import _native as nat
+from anrag import synth
+from anrag.index import Index
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
+iters = int(sys.argv[2]) if len(sys.argv) > 2 else 400
+dev = torch.device("cuda:0")
+post = synth.bm25_postings(n, 200_000, 777, dev)
+df = post["df"].cpu().numpy()
+idf = synth.bm25_idf(df, n)
+terms = synth.bm25_queries(post, 64, 99)
+torch.cuda.synchronize()
+idx = Index(0)
+idx.bm25_load(post["indptr"], (post["post_doc"].data_ptr(), post["post_doc"].numel()),
+              (post["post_tf"].data_ptr(), post["post_tf"].numel()), idf, post["doc_len"], float(post["total_len"]) / n,
+              synth.BM25_K1, synth.BM25_B)
+T = torch.full((64, 16), -1, dtype=torch.int32, device=dev)
+for i, t in enumerate(terms):
+    T[i, : len(t)] = torch.from_numpy(np.asarray(t, np.int32)).to(dev)
+nt = [len(t) for t in terms]
+out = torch.zeros((64, 25, 2), dtype=torch.int64, device=dev)
+torch.cuda.synchronize()
+lib = nat.load_library()
+alg = np.mean([sum(int(df[t]) for t in tl) * 12 for tl in terms])
+
+
+def step(i):
+    q = i % 64
+    nat.check(lib.anrag_bm25_search_device(idx.handle, T[q].data_ptr(), nt[q], 25, None, out[q].data_ptr()))
+
+
+for i in range(20):
+    step(i)
+idx.sync()
+idx.profile(True, kernels=[nat.KERNEL_BM25], every=4)
+idx.profile_reset()
+t0 = time.perf_counter()
+for i in range(iters):
+    step(i)
+idx.sync()
+wall = (time.perf_counter() - t0) / iters
+ms, launches = idx.profile_read(nat.KERNEL_BM25)
+k_us = ms / max(launches, 1) * 1e3
+print(f"n_docs={n}: {1/wall:.0f} q/s ({wall*1e6:.1f} us/query); K3 {k_us:.1f} us/launch; algorithmic "
+      f"{alg/1e6:.2f} MB/query -> {alg/(k_us*1e-6)/1e9:.0f} GB/s ({alg/(k_us*1e-6)/8e12*100:.1f}% of 8 TB/s); "
+      f"mean terms {np.mean(nt):.1f}, mean sum df {alg/12:.0f}")
