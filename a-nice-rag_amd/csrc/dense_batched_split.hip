@@ -85,43 +85,52 @@ __global__ __launch_bounds__(kSplitThreads, 2) void dense_batched_split_kernel(
         }
     };
     point_rows();
-    auto load_stage = [&]() {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) st_e[i] = *reinterpret_cast<const f32x4 *>(pe[i] + ld_ks * kBK);
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int f = tid + i * kSplitThreads;  // query row f>>2, 8-element chunk f&3
-            const int64_t off = (int64_t)(f >> 2) * dim + ld_ks * kBK + (f & 3) * 8;
-            st_qh[i] = *reinterpret_cast<const bf16x8 *>(q_hi + off);
-            st_ql[i] = *reinterpret_cast<const bf16x8 *>(q_lo + off);
-        }
+    // staged items: 0..3 corpus float4 (split into hi / lo while they are written to LDS), 4..5 query chunks
+    auto load_corpus = [&](int i) { st_e[i] = *reinterpret_cast<const f32x4 *>(pe[i] + ld_ks * kBK); };
+    auto load_query = [&](int i) {
+        const int f = tid + i * kSplitThreads;  // query row f>>2, 8-element chunk f&3
+        const int64_t off = (int64_t)(f >> 2) * dim + ld_ks * kBK + (f & 3) * 8;
+        st_qh[i] = *reinterpret_cast<const bf16x8 *>(q_hi + off);
+        st_ql[i] = *reinterpret_cast<const bf16x8 *>(q_lo + off);
+    };
+    auto advance_cursor = [&]() {
         if (++ld_ks == ksteps) {
             ld_ks = 0;
             ld_tile += tile_step;
             point_rows();
         }
     };
-    auto store_stage = [&](int buf) {
+    auto store_corpus = [&](int i, int buf) {
         unsigned char *base = lds + buf * kSplitBuf;
+        const int f = tid + i * kSplitThreads;
+        const f32x4 x = st_e[i];
+        const bf16x4 h = __builtin_convertvector(x, bf16x4);
+        const f32x4 r = x - __builtin_convertvector(h, f32x4);
+        const bf16x4 l = __builtin_convertvector(r, bf16x4);
+        const int c4 = f & 7;  // float4 index inside the 32-float row: 4 bf16 = half a 16-byte chunk
+        const int off = swz(f >> 3, c4 >> 1) + (c4 & 1) * 8;
+        *reinterpret_cast<bf16x4 *>(base + off) = h;
+        *reinterpret_cast<bf16x4 *>(base + kImgE + off) = l;
+    };
+    auto store_query = [&](int i, int buf) {
+        unsigned char *base = lds + buf * kSplitBuf;
+        const int f = tid + i * kSplitThreads;
+        const int off = swz(f >> 2, f & 3);
+        *reinterpret_cast<bf16x8 *>(base + 2 * kImgE + off) = st_qh[i];
+        *reinterpret_cast<bf16x8 *>(base + 2 * kImgE + kImgQ + off) = st_ql[i];
+    };
+    auto load_stage = [&]() {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int f = tid + i * kSplitThreads;
-            const f32x4 x = st_e[i];
-            const bf16x4 h = __builtin_convertvector(x, bf16x4);
-            const f32x4 r = x - __builtin_convertvector(h, f32x4);
-            const bf16x4 l = __builtin_convertvector(r, bf16x4);
-            const int c4 = f & 7;  // float4 index inside the 32-float row: 4 bf16 = half a 16-byte chunk
-            const int off = swz(f >> 3, c4 >> 1) + (c4 & 1) * 8;
-            *reinterpret_cast<bf16x4 *>(base + off) = h;
-            *reinterpret_cast<bf16x4 *>(base + kImgE + off) = l;
-        }
+        for (int i = 0; i < 4; ++i) load_corpus(i);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int f = tid + i * kSplitThreads;
-            const int off = swz(f >> 2, f & 3);
-            *reinterpret_cast<bf16x8 *>(base + 2 * kImgE + off) = st_qh[i];
-            *reinterpret_cast<bf16x8 *>(base + 2 * kImgE + kImgQ + off) = st_ql[i];
-        }
+        for (int i = 0; i < 2; ++i) load_query(i);
+        advance_cursor();
+    };
+    auto store_stage = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) store_corpus(i, buf);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) store_query(i, buf);
     };
 
     f32x16 acc[4][2];
@@ -132,18 +141,22 @@ __global__ __launch_bounds__(kSplitThreads, 2) void dense_batched_split_kernel(
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[ti][tj][r] = 0.f;
 
+    // Staging is dealt out between the MFMAs of a step, one item per slot (a slot = the three MFMAs of one
+    // accumulator tile): the registers holding step it+1 are written to the other LDS buffer in the first six slots,
+    // the loads of step it+2 follow at once.  A wave issues in order and the waves of the workgroup leave every
+    // barrier together, so staging as a block at the top of the step idled the matrix pipe (dense_batched.hip has
+    // the measurements).  Stores and loads also run on the last steps: the cursor clamps to the last row and
+    // nobody reads the buffer, and a branch around them would force vmcnt(0) waits.
     if (total > 0) {
         load_stage();
         store_stage(0);
-        if (total > 1) load_stage();
+        load_stage();
     }
     __syncthreads();
     int64_t cur_tile = first_tile;
     int cur_ks = 0;
     for (int64_t it = 0; it < total; ++it) {
         const int buf = (int)(it & 1);
-        if (it + 1 < total) store_stage(buf ^ 1);
-        if (it + 2 < total) load_stage();
         const unsigned char *base = lds + buf * kSplitBuf;
 #pragma unroll
         for (int s = 0; s < kBK / 16; ++s) {  // two k = 16 sub-steps per staged tile
@@ -160,6 +173,7 @@ __global__ __launch_bounds__(kSplitThreads, 2) void dense_batched_split_kernel(
                 bh[t] = *reinterpret_cast<const bf16x8 *>(base + 2 * kImgE + off);
                 bl[t] = *reinterpret_cast<const bf16x8 *>(base + 2 * kImgE + kImgQ + off);
             }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int ti = 0; ti < 4; ++ti)
 #pragma unroll
@@ -168,6 +182,17 @@ __global__ __launch_bounds__(kSplitThreads, 2) void dense_batched_split_kernel(
                     acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[ti], bh[tj], acc[ti][tj], 0, 0, 0);
                     acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ti], bl[tj], acc[ti][tj], 0, 0, 0);
                     acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ti], bh[tj], acc[ti][tj], 0, 0, 0);
+                    const int slot = s * 8 + ti * 2 + tj;  // 0..15
+                    if (slot < 10) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (slot < 4) store_corpus(slot, buf ^ 1);
+                        else if (slot < 6) store_query(slot - 4, buf ^ 1);
+                        else if (slot == 6) { load_corpus(0); load_corpus(1); }
+                        else if (slot == 7) { load_corpus(2); load_corpus(3); }
+                        else if (slot == 8) load_query(0);
+                        else { load_query(1); advance_cursor(); }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                 }
         }
         if (++cur_ks == ksteps) {
