@@ -116,6 +116,8 @@ struct anrag_index {
     // WRRF scratch
     int64_t *d_w_ids = nullptr, *d_w_in = nullptr;
     double *d_w_contrib = nullptr, *d_w_score = nullptr;
+    void *d_w_blob = nullptr;           // sort-based long form (sort_select.hip)
+    int64_t w_blob_bytes = 0;
     int32_t *d_w_first = nullptr, *d_w_count = nullptr;
     anrag_candidate *d_w_out = nullptr;
     int64_t wrrf_cap = 0;
@@ -195,6 +197,8 @@ int bm25_search_large_k(anrag_index *idx, hipStream_t stream, const int32_t *d_t
 // with id < 0 are padding.  Writes min(top_n, distinct) records to d_out and the count to *d_count.
 int ensure_wrrf_scratch(anrag_index *idx, int64_t n_entries);
 void free_wrrf_scratch(anrag_index *idx);
+int wrrf_sorted(anrag_index *idx, hipStream_t st, const int64_t *d_ids, const double *d_contrib, int32_t m,
+                int32_t top_n, anrag_candidate *d_out, int32_t *d_count);
 int launch_wrrf(anrag_index *idx, hipStream_t st, const int64_t *d_ids, const anrag_candidate *d_cands,
                 const int32_t *h_off, const double *h_weight, int32_t n_lists, double k, int32_t top_n,
                 anrag_candidate *d_out, int32_t *d_count);

@@ -16,6 +16,7 @@
 namespace anrag {
 
 constexpr int kWrrfSmall = 1024;
+constexpr int kWrrfAllPairsMax = 4096;  // above: sort-based form (sort_select.hip)
 
 struct WrrfLists {
     int32_t n;
@@ -140,7 +141,9 @@ __global__ __launch_bounds__(256) void wrrf_rank_kernel(const int64_t *__restric
 
 void free_wrrf_scratch(anrag_index *idx) {
     void *ptrs[] = {idx->d_w_ids, idx->d_w_in, idx->d_w_contrib, idx->d_w_score, idx->d_w_first, idx->d_w_out,
-                    idx->d_w_count};
+                    idx->d_w_count, idx->d_w_blob};
+    idx->d_w_blob = nullptr;
+    idx->w_blob_bytes = 0;
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     idx->d_w_ids = idx->d_w_in = nullptr;
@@ -187,6 +190,8 @@ int launch_wrrf(anrag_index *idx, hipStream_t st, const int64_t *d_ids, const an
     if (rc) return rc;
     const unsigned blocks = (unsigned)((m + 255) / 256);
     wrrf_contrib_kernel<<<blocks, 256, 0, st>>>(d_ids, d_cands, L, m, k, idx->d_w_ids, idx->d_w_contrib, d_count);
+    if (m > kWrrfAllPairsMax)  // long lists: three radix sorts instead of M^2 comparisons
+        return wrrf_sorted(idx, st, idx->d_w_ids, idx->d_w_contrib, m, top_n, d_out, d_count);
     wrrf_sum_kernel<<<blocks, 256, 0, st>>>(idx->d_w_ids, idx->d_w_contrib, m, idx->d_w_score, idx->d_w_first, d_count);
     wrrf_rank_kernel<<<blocks, 256, 0, st>>>(idx->d_w_ids, idx->d_w_score, idx->d_w_first, m, top_n, d_out);
     ANRAG_HIP(hipGetLastError());

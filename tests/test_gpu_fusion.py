@@ -31,19 +31,28 @@ def test_wrrf_golden_bitwise(idx):
             assert out_score.tolist() == [w[1] for w in want]
 
 
-def test_wrrf_long_lists_grid_form(idx):
+def test_wrrf_long_lists(idx):
+    """Lists beyond one workgroup: the all-pairs grid form (1,024 < M <= 4,096 entries) and the sort-based form
+    (retrieval_eval's full-ranking mode: two 12,000-id lists), with repeated ids inside a list, ids shared by all
+    lists, a zero weight and many equal scores -- bit-for-bit the dict + stable-sort result."""
     from oracle import ref_search
 
     rng = np.random.default_rng(1)
-    lists = [rng.permutation(9000)[:n].tolist() for n in (3000, 2500, 1200)]
-    names = ["a", "b", "c"]
-    weights = {"a": 5.0, "b": 1.0, "c": 2.0}
-    ref = ref_search.weighted_reciprocal_rank_fusion(list(zip(lists, names)), weights, 40)
-    for top_n in (len(ref), 12000, 15):
-        out_id, out_score = idx.wrrf(lists, [weights[n] for n in names], 40, top_n)
-        want = ref[:top_n]
-        assert out_id.tolist() == [i for i, _ in want]
-        assert out_score.tolist() == [s for _, s in want]
+    cases = [
+        ([rng.permutation(9000)[:n].tolist() for n in (1500, 900, 600)], {"a": 5.0, "b": 1.0, "c": 2.0}),     # grid
+        ([rng.permutation(9000)[:n].tolist() for n in (3000, 2500, 1200)], {"a": 5.0, "b": 1.0, "c": 2.0}),   # sorted
+        ([rng.permutation(12000).tolist(), rng.permutation(12000).tolist()], {"a": 5.0, "b": 1.0}),            # eval shape
+        ([rng.integers(0, 500, 4000).tolist(), rng.integers(0, 500, 3000).tolist(), list(range(2000))],
+         {"a": 1.0, "b": 1.0, "c": 0.0}),                                                                      # repeats, ties
+    ]
+    for lists, weights in cases:
+        names = list(weights)[: len(lists)]
+        ref = ref_search.weighted_reciprocal_rank_fusion(list(zip(lists, names)), weights, 40)
+        for top_n in (len(ref), 30000, 15):
+            out_id, out_score = idx.wrrf(lists, [weights[n] for n in names], 40, top_n)
+            want = ref[:top_n]
+            assert out_id.tolist() == [i for i, _ in want]
+            assert out_score.tolist() == [s for _, s in want]
 
 
 def test_hybrid_matches_oracle(idx):
