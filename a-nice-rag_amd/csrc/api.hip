@@ -214,6 +214,8 @@ int anrag_index_create(int device, anrag_index **out) {
     return ANRAG_OK;
 }
 
+static void free_host_slots(anrag_index *idx);
+
 static void free_dense(anrag_index *idx) {
     free_batched(idx);
     dev_free(idx, idx->d_emb, idx->n_rows * idx->dim);
@@ -241,6 +243,7 @@ int anrag_index_destroy(anrag_index *idx) {
             if (p) (void)hipFree(p);
         free_wrrf_scratch(idx);
         free_batched(idx);
+        free_host_slots(idx);
         if (idx->h_pinned) (void)hipHostFree(idx->h_pinned);
         for (hipEvent_t e : idx->event_pool) (void)hipEventDestroy(e);
         for (int b = 0; b < kPipeSlots; ++b) {
@@ -700,49 +703,152 @@ int anrag_hybrid_search_device(anrag_index *idx, const float *d_query, const int
                           d_allow_dense_bits, d_allow_bm25_bits, d_out, d_count);
 }
 
+// ---- host-pointer hybrid query.  Staging is per pipeline slot (pinned host block + device operands + result
+// records), and the caller holds the index lock only while it ENQUEUES: it waits for its own result outside the
+// lock, so callers on several threads (the reference shares one SearchEngine across Streamlit session threads,
+// src/app.py:17-27) overlap like back-to-back device calls do -- scans adjacent on the primary stream.
+static constexpr size_t kSlotTerms = 4096 * sizeof(int32_t), kSlotAllow = 2048 * sizeof(uint32_t),
+                        kSlotOut = 2 * ANRAG_FUSED_K_MAX * sizeof(anrag_candidate);
+
+static void free_host_slots(anrag_index *idx) {
+    for (auto &hs : idx->host_slot) {
+        if (hs.h) (void)hipHostFree(hs.h);
+        for (void *p : {(void *)hs.d_query, (void *)hs.d_terms, (void *)hs.d_allow_a, (void *)hs.d_allow_b,
+                        (void *)hs.d_out, (void *)hs.d_count})
+            if (p) (void)hipFree(p);
+        if (hs.done) (void)hipEventDestroy(hs.done);
+        hs = anrag_index::HostSlot();
+    }
+    idx->host_slot_dim = 0;
+}
+
+static int ensure_host_slots(anrag_index *idx, std::unique_lock<std::mutex> &lock) {
+    const int32_t dim = idx->dim > 0 ? idx->dim : 1;
+    if (idx->host_slot_dim == dim) return ANRAG_OK;
+    // re-sizing: nobody may still be reading a slot
+    idx->slot_cv.wait(lock, [&] {
+        for (const auto &hs : idx->host_slot)
+            if (hs.busy) return false;
+        return true;
+    });
+    if (idx->host_slot_dim == dim) return ANRAG_OK;  // another caller did it while this one waited
+    free_host_slots(idx);
+    const size_t qbytes = ((size_t)dim * sizeof(float) + 255) / 256 * 256;
+    for (auto &hs : idx->host_slot) {
+        ANRAG_HIP(hipHostMalloc(reinterpret_cast<void **>(&hs.h), qbytes + kSlotTerms + 2 * kSlotAllow + kSlotOut + 256,
+                                hipHostMallocDefault));
+        ANRAG_HIP(hipMalloc(reinterpret_cast<void **>(&hs.d_query), qbytes));
+        ANRAG_HIP(hipMalloc(reinterpret_cast<void **>(&hs.d_terms), kSlotTerms));
+        ANRAG_HIP(hipMalloc(reinterpret_cast<void **>(&hs.d_allow_a), kSlotAllow));
+        ANRAG_HIP(hipMalloc(reinterpret_cast<void **>(&hs.d_allow_b), kSlotAllow));
+        ANRAG_HIP(hipMalloc(reinterpret_cast<void **>(&hs.d_out), kSlotOut));
+        ANRAG_HIP(hipMalloc(reinterpret_cast<void **>(&hs.d_count), 256));
+        ANRAG_HIP(hipEventCreateWithFlags(&hs.done, hipEventDisableTiming));
+    }
+    idx->host_slot_dim = dim;
+    return ANRAG_OK;
+}
+
+// allow list (one byte per source) -> bitmap in the slot's pinned block -> device, asynchronously
+static int stage_allow_slot(hipStream_t st, const uint8_t *allow, int32_t n_sources, uint32_t *h_bits, uint32_t *d_bits,
+                            const uint32_t **out) {
+    *out = nullptr;
+    if (!allow) return ANRAG_OK;
+    ANRAG_REQUIRE(n_sources >= 0 && n_sources <= 65536, "n_sources %d out of range [0, 65536]", n_sources);
+    memset(h_bits, 0, kSlotAllow);
+    for (int32_t s = 0; s < n_sources; ++s)
+        if (allow[s]) h_bits[s >> 5] |= 1u << (s & 31);
+    ANRAG_HIP(hipMemcpyAsync(d_bits, h_bits, kSlotAllow, hipMemcpyHostToDevice, st));
+    *out = d_bits;
+    return ANRAG_OK;
+}
+
 int anrag_hybrid_search(anrag_index *idx, const float *query, const int32_t *term_ids, int32_t n_terms,
                         int32_t similarity_k, double w_dense, double w_bm25, double wrrf_k, int32_t top_n,
                         const uint8_t *allow_dense, int32_t n_dense_sources, const uint8_t *allow_bm25,
                         int32_t n_bm25_sources, int64_t *out_id, double *out_score, int32_t *out_count) {
-    ANRAG_ENTER(idx);
+    ANRAG_REQUIRE(idx != nullptr, "index handle is NULL");
+    std::unique_lock<std::mutex> lock(idx->mu);
+    DeviceGuard guard(idx->device);
+    if (!guard.ok) {
+        set_error("hipSetDevice(%d) failed", idx->device);
+        return ANRAG_ERR_HIP;
+    }
     ANRAG_REQUIRE(out_id && out_score && out_count, "NULL operand");
     ANRAG_REQUIRE(similarity_k > 0 && similarity_k <= ANRAG_FUSED_K_MAX, "fused hybrid serves 1 <= similarity_k <= %d",
                   ANRAG_FUSED_K_MAX);
     ANRAG_REQUIRE(top_n > 0 && top_n <= 2 * ANRAG_FUSED_K_MAX, "top_n %d out of range", top_n);
     ANRAG_REQUIRE(!(allow_dense && !idx->d_dense_src) && !(allow_bm25 && !idx->d_bm25_src),
                   "a source filter needs source ids");
+    ANRAG_REQUIRE(n_terms >= 0 && n_terms <= 4096, "n_terms %d out of range [0, 4096]", n_terms);
+    ANRAG_REQUIRE(n_terms == 0 || term_ids != nullptr, "term_ids is NULL");
+    const bool dense = idx->d_emb && w_dense > 0.0;
+    ANRAG_REQUIRE(!dense || query != nullptr, "query is NULL");
     int rc;
-    if ((rc = settle_pipeline(idx))) return rc;  // the staging buffers below are single
-    hipStream_t P = idx->primary, S = idx->secondary;
-    if ((rc = ensure_common_workspace(idx))) return rc;
-    if ((rc = ensure_wrrf_scratch(idx, 4096))) return rc;
-    char *pin = static_cast<char *>(idx->h_pinned);
-    const uint32_t *d_ad = nullptr, *d_ab = nullptr;
-    if ((rc = stage_allow(idx, P, allow_dense, n_dense_sources, idx->d_allow_a, reinterpret_cast<uint32_t *>(pin), &d_ad)))
-        return rc;
-    if ((rc = stage_allow(idx, S, allow_bm25, n_bm25_sources, idx->d_allow_b, reinterpret_cast<uint32_t *>(pin + 8192),
-                          &d_ab)))
-        return rc;
-    if (idx->d_emb && w_dense > 0.0) {
-        ANRAG_REQUIRE(query != nullptr, "query is NULL");
-        ANRAG_HIP(hipMemcpyAsync(idx->d_query, query, (size_t)idx->dim * sizeof(float), hipMemcpyHostToDevice, P));
+    if ((rc = ensure_host_slots(idx, lock))) return rc;
+    // the slot hybrid_enqueue is about to use; its host block is free once the previous caller has copied out
+    int s;
+    for (;;) {
+        s = (int)(idx->hyb_seq % kPipeSlots);
+        if (!idx->host_slot[s].busy) break;
+        idx->slot_cv.wait(lock);
     }
-    if ((rc = stage_terms(idx, S, term_ids, n_terms))) return rc;
-    if ((rc = hybrid_enqueue(idx, kTailFuse, idx->d_query, idx->d_terms, n_terms, similarity_k, w_dense, w_bm25, wrrf_k,
-                             top_n, d_ad, d_ab, idx->d_w_out, idx->d_w_count)))
+    anrag_index::HostSlot &hs = idx->host_slot[s];
+    hs.busy = true;
+    auto release = [&](bool relock) {
+        if (relock) lock.lock();
+        hs.busy = false;
+        lock.unlock();
+        idx->slot_cv.notify_all();
+    };
+    hipStream_t P = idx->primary, S = idx->secondary;
+    const size_t qbytes = ((size_t)idx->host_slot_dim * sizeof(float) + 255) / 256 * 256;
+    char *h_terms = hs.h + qbytes, *h_aa = h_terms + kSlotTerms, *h_ab = h_aa + kSlotAllow, *h_out = h_ab + kSlotAllow;
+    char *h_cnt = h_out + kSlotOut;
+    const uint32_t *d_ad = nullptr, *d_ab = nullptr;
+    auto enqueue = [&]() -> int {
+        int r;
+        if ((r = stage_allow_slot(P, allow_dense, n_dense_sources, reinterpret_cast<uint32_t *>(h_aa), hs.d_allow_a, &d_ad)))
+            return r;
+        if ((r = stage_allow_slot(S, allow_bm25, n_bm25_sources, reinterpret_cast<uint32_t *>(h_ab), hs.d_allow_b, &d_ab)))
+            return r;
+        if (dense) {
+            memcpy(hs.h, query, (size_t)idx->dim * sizeof(float));
+            ANRAG_HIP(hipMemcpyAsync(hs.d_query, hs.h, (size_t)idx->dim * sizeof(float), hipMemcpyHostToDevice, P));
+        }
+        if (n_terms > 0) {
+            memcpy(h_terms, term_ids, (size_t)n_terms * sizeof(int32_t));
+            ANRAG_HIP(hipMemcpyAsync(hs.d_terms, h_terms, (size_t)n_terms * sizeof(int32_t), hipMemcpyHostToDevice, S));
+        }
+        if ((r = hybrid_enqueue(idx, kTailFuse, hs.d_query, hs.d_terms, n_terms, similarity_k, w_dense, w_bm25, wrrf_k,
+                                top_n, d_ad, d_ab, hs.d_out, hs.d_count)))
+            return r;
+        // the fused tail runs on the secondary stream: the results follow it down
+        ANRAG_HIP(hipMemcpyAsync(h_out, hs.d_out, (size_t)top_n * sizeof(anrag_candidate), hipMemcpyDeviceToHost, S));
+        ANRAG_HIP(hipMemcpyAsync(h_cnt, hs.d_count, sizeof(int32_t), hipMemcpyDeviceToHost, S));
+        ANRAG_HIP(hipEventRecord(hs.done, S));
+        return ANRAG_OK;
+    };
+    if ((rc = enqueue())) {
+        (void)sync_all(idx);  // nothing of this query may still touch the slot
+        release(false);
         return rc;
-    anrag_candidate *h_cand = reinterpret_cast<anrag_candidate *>(pin + 16384);
-    int32_t *h_cnt = reinterpret_cast<int32_t *>(pin + 16384 + 4096);
-    if ((rc = sync_all(idx))) return rc;
-    ANRAG_HIP(hipMemcpyAsync(h_cand, idx->d_w_out, (size_t)top_n * sizeof(anrag_candidate), hipMemcpyDeviceToHost, P));
-    ANRAG_HIP(hipMemcpyAsync(h_cnt, idx->d_w_count, sizeof(int32_t), hipMemcpyDeviceToHost, P));
-    ANRAG_HIP(hipStreamSynchronize(P));
-    const int32_t cnt = std::min(*h_cnt, top_n);
+    }
+    lock.unlock();
+    const hipError_t e = hipEventSynchronize(hs.done);
+    if (e != hipSuccess) {
+        set_error("hipEventSynchronize failed: %s", hipGetErrorString(e));
+        release(true);
+        return ANRAG_ERR_HIP;
+    }
+    const anrag_candidate *h_cand = reinterpret_cast<const anrag_candidate *>(h_out);
+    const int32_t cnt = std::min(*reinterpret_cast<const int32_t *>(h_cnt), top_n);
     for (int32_t i = 0; i < cnt; ++i) {
         out_id[i] = h_cand[i].doc;
         out_score[i] = h_cand[i].score;
     }
     *out_count = cnt;
+    release(true);
     return ANRAG_OK;
 }
 

@@ -6,6 +6,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <limits>
+#include <condition_variable>
 #include <mutex>
 #include <vector>
 
@@ -64,6 +65,21 @@ struct anrag_index {
     hipEvent_t ev_fused[anrag::kPipeSlots] = {};   // tail of the slot finished: its lists may be overwritten
     uint64_t hyb_seq = 0;
     bool hyb_outstanding = false;
+    // host-pointer hybrid queries (anrag_hybrid_search): per-slot staging, so that callers on several threads
+    // overlap -- a caller holds the index lock while it enqueues, not while it waits for its result
+    struct HostSlot {
+        char *h = nullptr;            // pinned: query | terms | allow bitmaps | result records | count
+        float *d_query = nullptr;
+        int32_t *d_terms = nullptr;
+        uint32_t *d_allow_a = nullptr, *d_allow_b = nullptr;
+        anrag_candidate *d_out = nullptr;
+        int32_t *d_count = nullptr;
+        hipEvent_t done = nullptr;
+        bool busy = false;
+    };
+    HostSlot host_slot[anrag::kPipeSlots];
+    int32_t host_slot_dim = 0;        // dim the slots were sized for (0: not allocated)
+    std::condition_variable slot_cv;
 
     // ---- dense shard: row-major fp32, rows 16-byte aligned when dim % 4 == 0
     float *d_emb = nullptr;

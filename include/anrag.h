@@ -205,7 +205,8 @@ int anrag_wrrf(anrag_index *idx, const int64_t *ids, const int32_t *list_len,
  * (query_rag_retrieval.py:197-220, :304-335, :356-378) in one call: dense scan on
  * the primary stream, BM25 on the secondary, WRRF + top-n on the device.
  * n_terms == 0 or w_bm25 <= 0 skips BM25 (then the dense list is returned, :363-366).
- * allow_* as above, one per row space. */
+ * allow_* as above, one per row space.  Callers on several threads overlap: the
+ * index lock is held while a call enqueues, not while it waits for its result. */
 int anrag_hybrid_search(anrag_index *idx, const float *query, const int32_t *term_ids,
                         int32_t n_terms, int32_t similarity_k, double w_dense, double w_bm25,
                         double wrrf_k, int32_t top_n, const uint8_t *allow_dense,

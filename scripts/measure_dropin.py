@@ -88,6 +88,16 @@ for flt in (None, "CG,NG"):
     assert got[:8] == [ask(i, flt) for i in range(8)]
     print("retrieve_documents_batch filter=%r: %.0f q/s (%.1f us/query)" % (flt, 1 / dt, dt * 1e6), flush=True)
 
+# several caller threads on ONE system (the reference's Streamlit sessions): enqueues overlap
+from concurrent.futures import ThreadPoolExecutor
+for workers in (2, 4, 8):
+    with ThreadPoolExecutor(workers) as pool:
+        list(pool.map(ask, range(64)))
+        t1 = time.perf_counter()
+        list(pool.map(ask, range(nq)))
+        dt = (time.perf_counter() - t1) / nq
+    print("retrieve_documents from %d threads: %.0f q/s (%.1f us/query)" % (workers, 1 / dt, dt * 1e6), flush=True)
+
 # the raw ABI call underneath, same operands
 from anrag.database_manager import FusedPair
 pair = FusedPair.of(df, proxy, ids)

@@ -71,3 +71,48 @@ def test_mixed_bursts_match_serial():
         od = out_d.cpu().numpy()
         for i in range(nq):
             assert od[i, :, 1].tolist() == dense_ref[i].tolist()
+
+
+def test_concurrent_host_callers_match_serial():
+    """One index, many host threads (the reference shares one SearchEngine across Streamlit session threads,
+    src/app.py:17-27): `anrag_hybrid_search` callers overlap -- each holds the index lock only while it enqueues --
+    and are mixed with other entry points that drain the pipeline (dense / BM25 search, a source filter).  Every
+    answer must equal the serial one."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    from oracle.make_golden import synth_chunks, synth_dense
+    from anrag.bm25_index import Bm25Index
+    from anrag.index import Index
+
+    n, d = 40000, 256
+    chunks = [c for c in synth_chunks(n + 2000, 31) if c["tokens"]][:n]
+    corpus = [c["tokens"] for c in chunks]
+    e = synth_dense(n, d, 32)
+    bi = Bm25Index(corpus, 1.7, 0.83, 0.05)
+    table = {}
+    sid = np.array([table.setdefault(c["source"], len(table)) for c in chunks], dtype=np.uint16)
+    allow = (np.arange(len(table)) % 3 != 0).astype(np.uint8)
+    rng = np.random.default_rng(33)
+    nq = 96
+    rows = rng.integers(0, n, nq)
+    q = e[rows] + 0.05 * rng.standard_normal((nq, d), dtype=np.float32)
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    terms = [bi.term_ids([str(t) for t in rng.choice(corpus[r], size=int(rng.integers(1, 9)))]) for r in rows]
+    with Index(0) as idx:
+        idx.dense_load(e, source_id=sid)
+        idx.bm25_load(bi.indptr, bi.post_doc, bi.post_tf, bi.idf, bi.doc_len, bi.avgdl, bi.k1, bi.b, source_id=sid)
+
+        def ask(i):
+            kind = i % 8
+            if kind == 6:
+                return ("dense", idx.dense_search(q[i], 10)[0][0].tolist())
+            if kind == 7:
+                return ("bm25", idx.bm25_search(terms[i], 25)[0].tolist())
+            flt = allow if kind == 3 else None
+            ids, scores = idx.hybrid_search(q[i], terms[i], 25, 5.0, 1.0, 40, 10, flt, flt)
+            return ("hybrid", ids.tolist(), scores.tolist())
+
+        serial = [ask(i) for i in range(nq)]
+        for workers in (2, 8, 16):
+            with ThreadPoolExecutor(workers) as pool:
+                assert list(pool.map(ask, range(nq))) == serial, workers
