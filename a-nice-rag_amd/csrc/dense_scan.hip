@@ -198,8 +198,9 @@ int dense_scan_grid(const anrag_index *idx) {
 template <int G, int CH>
 static void launch_scan(int grid, hipStream_t st, const anrag_index *idx, const float *q, int32_t k,
                         const uint32_t *allow, float *scores_out, float *blk_s, uint32_t *blk_r) {
-    // ~6 dwordx4 per lane per batch, two batches in flight (sweep at 768-d: R=2 7.05, R=3 6.96, R=4 6.86 TB/s)
-    constexpr int R = CH >= 6 ? 1 : (CH >= 3 ? 2 : (CH == 2 ? 3 : 6));
+    // 4-6 dwordx4 per lane per batch, two batches in flight = 8-12 loads per lane (768-d: R=1 6.07, R=2 7.05, R=3 6.96,
+    // R=4 6.86 TB/s; 1024-d: R=1 7.0, R=2 6.8 TB/s)
+    constexpr int R = CH >= 4 ? 1 : (CH >= 3 ? 2 : (CH == 2 ? 3 : 6));
 #define ANRAG_SCAN(F, S)                                                                                     \
     dense_scan_kernel<G, CH, R, F, S><<<grid, kScanThreads, 0, st>>>(                                          \
         idx->d_emb, q, idx->n_rows, idx->dim, k, idx->d_dense_src, allow, blk_s, blk_r, scores_out)
@@ -224,7 +225,8 @@ int launch_dense_scan(anrag_index *idx, hipStream_t st, const float *d_query, in
         bool done = true;
         if (d % 256 == 0 && d / 256 <= 16) {
             switch (d / 256) {
-                case 1: launch_scan<64, 1>(grid, st, idx, d_query, k, allow, d_scores_out, blk_s, blk_r); break;
+                case 1: launch_scan<32, 2>(grid, st, idx, d_query, k, allow, d_scores_out, blk_s, blk_r); break;  // 256-d: two rows per
+                                                                                                         // load (<64,1>: 65 % of HBM peak, this: 86 %)
                 case 2: launch_scan<64, 2>(grid, st, idx, d_query, k, allow, d_scores_out, blk_s, blk_r); break;
                 case 3: launch_scan<64, 3>(grid, st, idx, d_query, k, allow, d_scores_out, blk_s, blk_r); break;
                 case 4: launch_scan<64, 4>(grid, st, idx, d_query, k, allow, d_scores_out, blk_s, blk_r); break;
