@@ -62,6 +62,7 @@ _SIGNATURES = {
     "anrag_hybrid_search_batch": [_p, _p, _p, _p, _i32, _i32, _f64, _f64, _f64, _i32, _p, _i32, _p, _i32, _p, _p, _p],
     "anrag_merge_candidates_device": [_p, _p, _i32, _i32, _i64, _p],
     "anrag_hybrid_candidates_device": [_p, _p, _p, _i32, _i32, _p, _p, _p],
+    "anrag_hybrid_candidates_group_device": [_p, _p, _p, _p, _i32, _i32, _p, _p, _p],
     "anrag_merge_fuse_device": [_p, _p, _i32, _i32, _i64, _f64, _f64, _f64, _i32, _i32, _p, _p],
     "anrag_wrrf_device": [_p, _p, _i32, _p, _i32, _f64, _f64, _f64, _i32, _p, _p],
     "anrag_hybrid_search_device": [_p, _p, _p, _i32, _i32, _f64, _f64, _f64, _i32, _p, _p, _p, _p],
@@ -73,6 +74,7 @@ _SIGNATURES = {
     "anrag_profile_set_sampling": [_p, _i32],
     "anrag_profile_reset": [_p],
     "anrag_profile_read": [_p, C.c_int, C.POINTER(_f64), C.POINTER(_i64)],
+    "anrag_profile_read_units": [_p, C.c_int, C.POINTER(_i64)],
     "anrag_index_info": [_p, C.POINTER(_i64), C.POINTER(_i32), C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)],
 }
 EXPORTS = tuple(_SIGNATURES) + ("anrag_last_error",)

@@ -18,6 +18,7 @@ constexpr int kWave = 64;            // CDNA wavefront
 constexpr int kListLen = 64;         // one top-k slot per lane (ANRAG_FUSED_K_MAX)
 constexpr int kScanThreads = 256;    // 4 waves: one scan workgroup per CU (sweep: profiles/r01_scan_config_sweep.txt)
 constexpr int kScanWaves = kScanThreads / kWave;
+constexpr int kScanGroupMax = 8;   // queries one scan launch can carry (dense_scan.hip)
 constexpr int kPipeSlots = 8;      // queries in flight in the hybrid pipeline (list sets, events)
 constexpr int kMaxScanBlocks = 256;  // one per CU; also bounds the final merge fan-in
 constexpr uint32_t kNoRow = 0xFFFFFFFFu;
@@ -45,6 +46,7 @@ void set_error(const char *fmt, ...);
 struct ProfSpan {
     int kernel;
     hipEvent_t start, stop;
+    int units;  // queries the bracketed launch carried
 };
 
 }  // namespace anrag
@@ -150,6 +152,7 @@ struct anrag_index {
     std::vector<hipEvent_t> event_pool;
     double prof_ms[ANRAG_KERNEL_COUNT] = {0};
     int64_t prof_launches[ANRAG_KERNEL_COUNT] = {0};
+    int64_t prof_units[ANRAG_KERNEL_COUNT] = {0};
 };
 
 namespace anrag {
@@ -169,7 +172,8 @@ struct LaunchTimer {
     hipStream_t stream;
     int kernel;
     hipEvent_t start = nullptr, stop = nullptr;
-    LaunchTimer(anrag_index *i, int k, hipStream_t s);
+    int units;
+    LaunchTimer(anrag_index *i, int k, hipStream_t s, int units = 1);
     ~LaunchTimer();
 };
 
@@ -180,6 +184,8 @@ int dense_scan_grid(const anrag_index *idx);
 // K1 alone: one sorted list per workgroup into block-list set `set` (or every score into d_scores_out, k = 0)
 int launch_dense_scan(anrag_index *idx, hipStream_t stream, const float *d_query, int32_t k,
                       const uint32_t *d_allow_bits, float *d_scores_out, int set);
+int launch_dense_scan_group(anrag_index *idx, hipStream_t stream, const float *const *d_queries, int32_t n_queries,
+                            int32_t k, const uint32_t *d_allow_bits, float *d_scores_out, const int *sets);
 int launch_bm25_lists(anrag_index *idx, hipStream_t st, const int32_t *d_terms, int32_t n_terms, int32_t k,
                       const uint32_t *d_allow_bits, double *d_scores_out, int set);
 // Tail of a query, ONE launch (tail.hip): merge the dense block lists of set `set` and/or the BM25 partition

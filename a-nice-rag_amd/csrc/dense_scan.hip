@@ -58,11 +58,21 @@ __device__ __forceinline__ float group_sum(float v) {
 // R  row-groups in flight per wave iteration
 // FILTER  rows carry a source id and an allow bitmap is applied before selection
 // SCORES  write every row's score (large-k path / anrag_dense_scores) instead of selecting
+// The queries of one launch: each is scanned on its own (one pass over the matrix per query, batch = 1 arithmetic
+// and traffic); a workgroup goes on to the next query as soon as it has finished its share of this one -- no
+// grid-wide step between queries, so launch gap, ramp and the spread of the workgroups' finishing times are paid
+// once per launch instead of once per query.
+struct ScanQueries {
+    const float *q[kScanGroupMax];
+    float *blk_s[kScanGroupMax];
+    uint32_t *blk_r[kScanGroupMax];
+    int32_t n;
+};
+
 template <int G, int CH, int R, bool FILTER, bool SCORES, int THREADS = kScanThreads>
 __global__ __launch_bounds__(THREADS) void dense_scan_kernel(
-    const float *__restrict__ emb, const float *__restrict__ query, int64_t n_rows, int32_t dim, int32_t k,
-    const uint16_t *__restrict__ src, const uint32_t *__restrict__ allow_bits, float *__restrict__ blk_score,
-    uint32_t *__restrict__ blk_row, float *__restrict__ scores_out) {
+    const float *__restrict__ emb, ScanQueries Q, int64_t n_rows, int32_t dim, int32_t k,
+    const uint16_t *__restrict__ src, const uint32_t *__restrict__ allow_bits, float *__restrict__ scores_out) {
     constexpr int GROUPS = kWave / G;  // rows per wave-load
     constexpr int RW = GROUPS * R;     // rows per wave iteration
     constexpr int WAVES = THREADS / kWave;
@@ -81,6 +91,10 @@ __global__ __launch_bounds__(THREADS) void dense_scan_kernel(
 
     const f32x4 *__restrict__ ev = reinterpret_cast<const f32x4 *>(emb);
     const int64_t row_f4 = dim / 4;
+  for (int32_t qi = 0; qi < Q.n; ++qi) {
+    const float *__restrict__ query = Q.q[qi];
+    float *__restrict__ blk_score = Q.blk_s[qi];
+    uint32_t *__restrict__ blk_row = Q.blk_r[qi];
     f32x4 q[CH];
 #pragma unroll
     for (int c = 0; c < CH; ++c) q[c] = reinterpret_cast<const f32x4 *>(query)[c * G + sub];
@@ -147,6 +161,7 @@ __global__ __launch_bounds__(THREADS) void dense_scan_kernel(
             blk_row[blockIdx.x * kListLen + lane] = top.r;
         }
     }
+  }
 }
 
 // Any dim: one wave per row, scalar strided loads, query from global (L2).  Correctness path for
@@ -196,14 +211,14 @@ int dense_scan_grid(const anrag_index *idx) {
 }
 
 template <int G, int CH>
-static void launch_scan(int grid, hipStream_t st, const anrag_index *idx, const float *q, int32_t k,
-                        const uint32_t *allow, float *scores_out, float *blk_s, uint32_t *blk_r) {
+static void launch_scan(int grid, hipStream_t st, const anrag_index *idx, const ScanQueries &q, int32_t k,
+                        const uint32_t *allow, float *scores_out) {
     // 4-6 dwordx4 per lane per batch, two batches in flight = 8-12 loads per lane (768-d: R=1 6.07, R=2 7.05, R=3 6.96,
     // R=4 6.86 TB/s; 1024-d: R=1 7.0, R=2 6.8 TB/s)
     constexpr int R = CH >= 4 ? 1 : (CH >= 3 ? 2 : (CH == 2 ? 3 : 6));
 #define ANRAG_SCAN(F, S)                                                                                     \
     dense_scan_kernel<G, CH, R, F, S><<<grid, kScanThreads, 0, st>>>(                                          \
-        idx->d_emb, q, idx->n_rows, idx->dim, k, idx->d_dense_src, allow, blk_s, blk_r, scores_out)
+        idx->d_emb, q, idx->n_rows, idx->dim, k, idx->d_dense_src, allow, scores_out)
     if (scores_out) {
         if (allow) ANRAG_SCAN(true, true); else ANRAG_SCAN(false, true);
     } else {
@@ -214,51 +229,71 @@ static void launch_scan(int grid, hipStream_t st, const anrag_index *idx, const 
 
 int launch_dense_scan(anrag_index *idx, hipStream_t st, const float *d_query, int32_t k,
                       const uint32_t *d_allow_bits, float *d_scores_out, int set) {
+    return launch_dense_scan_group(idx, st, &d_query, 1, k, d_allow_bits, d_scores_out, &set);
+}
+
+// n <= kScanGroupMax queries in ONE launch, query i into block-list set sets[i] (d_scores_out: n == 1 only)
+int launch_dense_scan_group(anrag_index *idx, hipStream_t st, const float *const *d_queries, int32_t n_queries, int32_t k,
+                            const uint32_t *d_allow_bits, float *d_scores_out, const int *sets) {
+    ANRAG_REQUIRE(n_queries >= 1 && n_queries <= kScanGroupMax, "scan group of %d queries", n_queries);
+    ANRAG_REQUIRE(!d_scores_out || n_queries == 1, "score output serves one query per launch");
     const int64_t n = idx->n_rows;
-    float *blk_s = idx->d_blk_score_f32 + (int64_t)set * kMaxScanBlocks * kListLen;
-    uint32_t *blk_r = idx->d_blk_row_a + (int64_t)set * kMaxScanBlocks * kListLen;
+    ScanQueries Q;
+    Q.n = n_queries;
+    for (int i = 0; i < kScanGroupMax; ++i) {
+        const int j = i < n_queries ? i : 0;
+        Q.q[i] = d_queries[j];
+        Q.blk_s[i] = idx->d_blk_score_f32 + (int64_t)sets[j] * kMaxScanBlocks * kListLen;
+        Q.blk_r[i] = idx->d_blk_row_a + (int64_t)sets[j] * kMaxScanBlocks * kListLen;
+    }
+    const float *d_query = d_queries[0];
+    float *blk_s = Q.blk_s[0];
+    uint32_t *blk_r = Q.blk_r[0];
     const int d = idx->dim;
     const int grid = dense_scan_grid(idx);
     const uint32_t *allow = (idx->d_dense_src != nullptr) ? d_allow_bits : nullptr;
     {
-        LaunchTimer t(idx, ANRAG_KERNEL_DENSE_SCAN, st);
+        LaunchTimer t(idx, ANRAG_KERNEL_DENSE_SCAN, st, n_queries);
         bool done = true;
         if (d % 256 == 0 && d / 256 <= 16) {
             switch (d / 256) {
-                case 1: launch_scan<32, 2>(grid, st, idx, d_query, k, allow, d_scores_out, blk_s, blk_r); break;  // 256-d: two rows per
+                case 1: launch_scan<32, 2>(grid, st, idx, Q, k, allow, d_scores_out); break;  // 256-d: two rows per
                                                                                                          // load (<64,1>: 65 % of HBM peak, this: 86 %)
-                case 2: launch_scan<64, 2>(grid, st, idx, d_query, k, allow, d_scores_out, blk_s, blk_r); break;
-                case 3: launch_scan<64, 3>(grid, st, idx, d_query, k, allow, d_scores_out, blk_s, blk_r); break;
-                case 4: launch_scan<64, 4>(grid, st, idx, d_query, k, allow, d_scores_out, blk_s, blk_r); break;
-                case 6: launch_scan<64, 6>(grid, st, idx, d_query, k, allow, d_scores_out, blk_s, blk_r); break;
-                case 8: launch_scan<64, 8>(grid, st, idx, d_query, k, allow, d_scores_out, blk_s, blk_r); break;
-                case 12: launch_scan<64, 12>(grid, st, idx, d_query, k, allow, d_scores_out, blk_s, blk_r); break;  // 3072
-                case 16: launch_scan<64, 16>(grid, st, idx, d_query, k, allow, d_scores_out, blk_s, blk_r); break;  // 4096
+                case 2: launch_scan<64, 2>(grid, st, idx, Q, k, allow, d_scores_out); break;
+                case 3: launch_scan<64, 3>(grid, st, idx, Q, k, allow, d_scores_out); break;
+                case 4: launch_scan<64, 4>(grid, st, idx, Q, k, allow, d_scores_out); break;
+                case 6: launch_scan<64, 6>(grid, st, idx, Q, k, allow, d_scores_out); break;
+                case 8: launch_scan<64, 8>(grid, st, idx, Q, k, allow, d_scores_out); break;
+                case 12: launch_scan<64, 12>(grid, st, idx, Q, k, allow, d_scores_out); break;  // 3072
+                case 16: launch_scan<64, 16>(grid, st, idx, Q, k, allow, d_scores_out); break;  // 4096
                 default: done = false;
             }
         } else if (d % 128 == 0 && d / 128 <= 8) {
             switch (d / 128) {
-                case 1: launch_scan<32, 1>(grid, st, idx, d_query, k, allow, d_scores_out, blk_s, blk_r); break;
-                case 3: launch_scan<32, 3>(grid, st, idx, d_query, k, allow, d_scores_out, blk_s, blk_r); break;
-                case 5: launch_scan<32, 5>(grid, st, idx, d_query, k, allow, d_scores_out, blk_s, blk_r); break;
-                case 7: launch_scan<32, 7>(grid, st, idx, d_query, k, allow, d_scores_out, blk_s, blk_r); break;
+                case 1: launch_scan<32, 1>(grid, st, idx, Q, k, allow, d_scores_out); break;
+                case 3: launch_scan<32, 3>(grid, st, idx, Q, k, allow, d_scores_out); break;
+                case 5: launch_scan<32, 5>(grid, st, idx, Q, k, allow, d_scores_out); break;
+                case 7: launch_scan<32, 7>(grid, st, idx, Q, k, allow, d_scores_out); break;
                 default: done = false;
             }
         } else if (d % 64 == 0 && d / 64 <= 8) {
             switch (d / 64) {
-                case 1: launch_scan<16, 1>(grid, st, idx, d_query, k, allow, d_scores_out, blk_s, blk_r); break;
-                case 3: launch_scan<16, 3>(grid, st, idx, d_query, k, allow, d_scores_out, blk_s, blk_r); break;
-                case 5: launch_scan<16, 5>(grid, st, idx, d_query, k, allow, d_scores_out, blk_s, blk_r); break;
-                case 7: launch_scan<16, 7>(grid, st, idx, d_query, k, allow, d_scores_out, blk_s, blk_r); break;
+                case 1: launch_scan<16, 1>(grid, st, idx, Q, k, allow, d_scores_out); break;
+                case 3: launch_scan<16, 3>(grid, st, idx, Q, k, allow, d_scores_out); break;
+                case 5: launch_scan<16, 5>(grid, st, idx, Q, k, allow, d_scores_out); break;
+                case 7: launch_scan<16, 7>(grid, st, idx, Q, k, allow, d_scores_out); break;
                 default: done = false;
             }
         } else {
             done = false;
         }
-        if (!done)
-            dense_scan_topk_generic_kernel<<<grid, kScanThreads, 0, st>>>(idx->d_emb, d_query, n, d, k,
-                                                                          idx->d_dense_src, allow, blk_s, blk_r,
-                                                                          d_scores_out);
+        if (!done) {  // odd dimensions: one launch per query
+            (void)d_query; (void)blk_s; (void)blk_r;
+            for (int i = 0; i < n_queries; ++i)
+                dense_scan_topk_generic_kernel<<<grid, kScanThreads, 0, st>>>(idx->d_emb, Q.q[i], n, d, k,
+                                                                              idx->d_dense_src, allow, Q.blk_s[i],
+                                                                              Q.blk_r[i], d_scores_out);
+        }
         ANRAG_HIP(hipGetLastError());
     }
     return ANRAG_OK;

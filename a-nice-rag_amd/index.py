@@ -247,6 +247,12 @@ class Index:
         nat.check(self._lib.anrag_profile_read(self.handle, int(kernel_id), C.byref(ms), C.byref(n)))
         return ms.value, n.value
 
+    def profile_units(self, kernel_id: int) -> int:
+        """Queries the timed launches of a kernel carried (K1 launches carry up to 4 for query groups)."""
+        n = C.c_int64(0)
+        nat.check(self._lib.anrag_profile_read_units(self.handle, int(kernel_id), C.byref(n)))
+        return n.value
+
     def info(self) -> dict:
         a, d, b, p, h = C.c_int64(), C.c_int32(), C.c_int64(), C.c_int64(), C.c_int64()
         nat.check(self._lib.anrag_index_info(self.handle, C.byref(a), C.byref(d), C.byref(b), C.byref(p), C.byref(h)))

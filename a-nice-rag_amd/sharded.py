@@ -6,8 +6,9 @@ The reference has no distributed code at all; this is the 
 
 Per query, on every rank:
     1. local legs          K1 dense scan + K3 BM25 on the rank's rows, tail kernel -> 2k candidate records
-                           (`anrag_hybrid_candidates_device`: scan on the compute stream, BM25 on the
-                           index's second stream, tail + copy-out on the communication stream)
+                           (`anrag_hybrid_candidates_group_device`: scans on the compute stream -- the queries of
+                           an exchange group share scan launches, 4 per launch, each still its own pass --, BM25
+                           on the index's second stream, tail + copy-out on the communication stream)
     2. exchange            all-gather of the candidate records -- 2k x 16 B per query and rank (k=25: 800 B):
                            latency-bound, nowhere near the 7 x 153 GB/s xGMI links.  It runs on a separate
                            communication stream under the following scans, and `group` in-flight queries
@@ -65,6 +66,17 @@ class HipShardEngine:
             self.index.handle, d_query.data_ptr(), d_terms.data_ptr() if n_terms else None, n_terms, k, None, None,
             out.data_ptr()))
 
+    def legs_group(self, queries, terms, n_terms, k: int, outs) -> None:
+        """`legs` for the queries of one exchange group in ONE library call: the shard is scanned once per query,
+        but in a single launch per group of 4 (`anrag_hybrid_candidates_group_device`)."""
+        import ctypes as C
+
+        n = len(queries)
+        ptrs = lambda ts: (C.c_void_p * n)(*[t.data_ptr() for t in ts])
+        self._nat.check(self._lib.anrag_hybrid_candidates_group_device(
+            self.index.handle, ptrs(queries), ptrs(terms), (C.c_int32 * n)(*[int(x) for x in n_terms]), n, k, None, None,
+            ptrs(outs)))
+
     def merge_fuse(self, lists: torch.Tensor, n_lists: int, k: int, stride: int, w_dense: float, w_bm25: float,
                    wrrf_k: float, top_n: int, n_queries: int, out: torch.Tensor, count: torch.Tensor) -> None:
         self._nat.check(self._lib.anrag_merge_fuse_device(
@@ -98,12 +110,19 @@ class ShardedSearcher:
         self.count = [torch.zeros(self.group, dtype=torch.int32, device=self.device) for _ in range(self.depth)]
         self._slot = 0
         self._filled = 0
+        self._grouped = self.group > 1 and hasattr(engine, "legs_group")
+        self._pending: List[tuple] = []
 
     def submit(self, d_query: torch.Tensor, d_terms: torch.Tensor, n_terms: int) -> Tuple[int, int]:
         slot, g = self._slot, self._filled
         # the engine writes send[slot][g] in communication-stream order, so the slot's previous all-gather
         # (same stream) has finished with it: no events needed
-        self.engine.legs(d_query, d_terms, n_terms, self.k, self.send[slot][g])
+        if self._grouped:
+            # the local legs of a whole exchange group go to the engine together at flush(): one scan launch per
+            # group (the caller keeps the query tensors alive until then -- they are rows of its own buffers)
+            self._pending.append((d_query, d_terms, int(n_terms), self.send[slot][g]))
+        else:
+            self.engine.legs(d_query, d_terms, n_terms, self.k, self.send[slot][g])
         self._filled += 1
         if self._filled == self.group:
             self.flush()
@@ -115,6 +134,10 @@ class ShardedSearcher:
         if n == 0:
             return
         slot, eng, k = self._slot, self.engine, self.k
+        if self._pending:
+            qs, ts, nts, outs = zip(*self._pending)
+            eng.legs_group(qs, ts, nts, k, outs)
+            self._pending = []
         ctx = torch.cuda.stream(eng.comm_stream) if self.cuda else _NullCtx()
         with ctx:
             if self.distributed:

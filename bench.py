@@ -212,6 +212,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     scan_ms, scan_n = idx.profile_read(main_kernel)
+    scan_units = idx.profile_units(main_kernel)  # queries the timed launches carried (sharded: 4 per K1 launch)
     idx.profile(False)
     if world > 1:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
@@ -237,8 +238,10 @@ def main():
     if rank == 0:
         scan_avg_ms = scan_ms / max(scan_n, 1)
         # N*D*4 per query (this rank's rows), + N*2 with a filter
-        alg_bytes = n_local * args.dim * 4 + (n_local * 2 if args.filter else 0)
-        achieved = alg_bytes / (scan_avg_ms * 1e-3) / 1e9 if scan_n else 0.0
+        per_query_bytes = n_local * args.dim * 4 + (n_local * 2 if args.filter else 0)
+        queries_per_launch = (scan_units / scan_n) if (scan_n and not batched) else 1.0
+        alg_bytes = per_query_bytes * queries_per_launch  # a K1 launch of the sharded path scans a GROUP of queries,
+        achieved = alg_bytes / (scan_avg_ms * 1e-3) / 1e9 if scan_n else 0.0  # each its own pass over the shard
         traffic = None
         pmc = os.path.join(REPO, "profiles", "pmc_dense_scan.json")
         if os.path.exists(pmc):
@@ -246,7 +249,9 @@ def main():
                 with open(pmc) as f:
                     rec = json.load(f)
                 if rec.get("rows") == n_local and rec.get("dim") == args.dim:
-                    traffic = rec.get("hbm_bytes_per_launch")
+                    traffic = rec.get("hbm_bytes_per_launch")  # measured on one-query launches
+                    if traffic is not None:
+                        traffic = traffic * queries_per_launch
             except Exception:
                 traffic = None
         per_step = args.batch if batched else 1
@@ -281,6 +286,7 @@ def main():
                 "kernel": "dense_scan_kernel (K1)", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": scan_avg_ms, "launches": scan_n,
+                "queries_per_launch": queries_per_launch,
             },
             "index_build_s": build_s,
         }

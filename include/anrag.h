@@ -262,6 +262,18 @@ int anrag_hybrid_candidates_device(anrag_index *idx, const float *d_query,
                                    const int32_t *d_term_ids, int32_t n_terms, int32_t k,
                                    const uint32_t *d_allow_dense_bits,
                                    const uint32_t *d_allow_bm25_bits, anrag_candidate *d_out);
+
+/* The same for n_queries queries in one call: d_queries / d_term_ids / d_out are HOST
+ * arrays of device pointers, n_terms a host array.  The library scans the queries in
+ * groups of 4 per launch (each query still its own pass over the shard) -- at the
+ * shard sizes of 8 GPUs that is worth 10-14 % over n single calls.  What the sharded
+ * searcher calls once per exchange group. */
+int anrag_hybrid_candidates_group_device(anrag_index *idx, const float *const *d_queries,
+                                         const int32_t *const *d_term_ids,
+                                         const int32_t *n_terms, int32_t n_queries, int32_t k,
+                                         const uint32_t *d_allow_dense_bits,
+                                         const uint32_t *d_allow_bm25_bits,
+                                         anrag_candidate *const *d_out);
 /* The whole global tail of a GROUP of sharded queries in ONE launch (fusion
  * stream).  d_lists is the all-gather receive buffer: shard l's slab starts at
  * d_lists + l*list_stride and holds n_queries blocks of 2k records, block q as
@@ -301,6 +313,9 @@ int anrag_profile_enable(anrag_index *idx, uint32_t kernel_mask);
 int anrag_profile_set_sampling(anrag_index *idx, int32_t every_n);
 int anrag_profile_reset(anrag_index *idx);
 int anrag_profile_read(anrag_index *idx, int kernel_id, double *out_total_ms, int64_t *out_launches);
+/* Queries the timed launches of a kernel carried (a K1 launch carries up to 4 when the
+ * caller submits query groups): algorithmic bytes per launch = units / launches x N*D*4. */
+int anrag_profile_read_units(anrag_index *idx, int kernel_id, int64_t *out_units);
 /* Shape facts a caller needs for roofline arithmetic. */
 int anrag_index_info(anrag_index *idx, int64_t *dense_rows, int32_t *dense_dim,
                      int64_t *bm25_docs, int64_t *bm25_postings, int64_t *hbm_bytes);

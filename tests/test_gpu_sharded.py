@@ -41,8 +41,6 @@ def test_sharded_pipeline_world1_rccl():
         idx.dense_load(e, doc_id_base=1000)
         idx.bm25_load(bi.indptr, bi.post_doc, bi.post_tf, bi.idf, bi.doc_len, bi.avgdl, bi.k1, bi.b, doc_id_base=1000)
         engine = HipShardEngine(idx, device)
-        searcher = ShardedSearcher(engine, k=k, top_n=top_n, w_dense=5.0, w_bm25=1.0, wrrf_k=40, depth=4, group=3,
-                                   device=device)
         rng = np.random.default_rng(3)
         queries, toks_all = [], []
         for i in range(4):
@@ -56,7 +54,12 @@ def test_sharded_pipeline_world1_rccl():
             t = bi.term_ids(toks)
             T[i, : len(t)] = torch.from_numpy(t).to(device)
             nt.append(len(t))
-        for rounds in range(3):  # 12 submissions through 4 slots, drained once per round
+        # group=3: the local legs of an exchange group go to the library in one call (grouped scan launches, a
+        # partial group at drain); group=1: one call per query
+        for rounds, group in ((0, 3), (1, 3), (2, 1), (3, 4)):  # 16 submissions through 4 slots, drained once per round
+            if rounds in (0, 2, 3):
+                searcher = ShardedSearcher(engine, k=k, top_n=top_n, w_dense=5.0, w_bm25=1.0, wrrf_k=40, depth=4,
+                                           group=group, device=device)
             slots = [searcher.submit(Q[i], T[i], nt[i]) for i in range(4)]
             searcher.drain()
             for i, slot in enumerate(slots):
