@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Dense-only queries submitted n at a time to anrag_dense_search_device: the library scans them in groups
-(ANRAG_EXP_SCAN_GROUP, default 4) of one launch each.  usage: python scripts/microbench_group.py rows [n_per_call]"""
+"""Dense-only queries submitted n at a time to anrag_dense_search_device: the library scans them in groups of 4
+per launch (api.hip kScanGroup), each query its own pass over the matrix.  n_per_call = 1 shows the one-launch-per-
+query rate.  usage: python scripts/microbench_group.py rows [n_per_call]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -28,4 +29,4 @@ ids = out.cpu().numpy()[:, :, 1]
 print("ids match torch:", bool((ids == ref).all()))
 calls = 2000 // per
 t0 = time.perf_counter(); run(calls); dt = time.perf_counter() - t0
-print(f"rows={n} group={os.environ.get('ANRAG_EXP_SCAN_GROUP','4')} per_call={per}: {calls*per/dt:.0f} q/s ({dt/(calls*per)*1e6:.1f} us/query)")
+print(f"rows={n} queries_per_call={per}: {calls*per/dt:.0f} q/s ({dt/(calls*per)*1e6:.1f} us/query)")
