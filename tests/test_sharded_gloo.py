@@ -87,7 +87,15 @@ class OracleShardEngine:
             count[q] = len(fused)
 
 
-def _worker(rank, world, port, ret):
+class GroupedOracleShardEngine(OracleShardEngine):
+    """The same with the product engine's group call, so that the searcher takes its deferred-legs route."""
+
+    def legs_group(self, queries, terms, n_terms, k, outs):
+        for q, t, nt, out in zip(queries, terms, n_terms, outs):
+            self.legs(q, t, nt, k, out)
+
+
+def _worker(rank, world, port, ret, grouped=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -99,7 +107,7 @@ def _worker(rank, world, port, ret):
     e = synth_dense(n, d, 6)
     glob = CsrBM25(corpus, k1=1.7, b=0.83, epsilon=0.05)
     lo, hi = shard_bounds(n, world, rank)
-    eng = OracleShardEngine(e[lo:hi], lo, glob, corpus[lo:hi])
+    eng = (GroupedOracleShardEngine if grouped else OracleShardEngine)(e[lo:hi], lo, glob, corpus[lo:hi])
     rng = np.random.default_rng(11)
     ok = True
     for group in (1, 3):  # one query per all-gather, and grouped exchanges with a partial last group
@@ -141,11 +149,14 @@ def test_shard_bounds_cover_rows():
             assert max(sizes) - min(sizes) <= 1
 
 
-def test_sharded_search_world_size_2_gloo():
+@pytest.mark.parametrize("world,grouped", [(2, False), (3, True)])
+def test_sharded_search_gloo(world, grouped):
+    """world 2: one engine call per query; world 3 (uneven shards: 101/100/100 rows): the exchange group's legs in
+    one engine call, as the HIP engine takes them."""
     ctx = mp.get_context("spawn")
     ret = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, ret)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, ret, grouped)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
