@@ -132,6 +132,8 @@ int anrag_dense_search(anrag_index *idx, const float *queries, int32_t n_queries
  * anrag_candidate.  The scans run back to back on the primary stream, each
  * query's list merge on the fusion stream under the next scan: results are
  * complete in fusion-stream order (anrag_index_sync waits for everything).
+ * n_queries > 1: up to 4 queries share a scan launch (each is still its own pass
+ * over the matrix; a workgroup starts the next query when it has finished this one).
  * d_allow_bits: nullable device bitmap, bit s of word s/32 = source s allowed. */
 int anrag_dense_search_device(anrag_index *idx, const float *d_queries, int32_t n_queries,
                               int32_t k, const uint32_t *d_allow_bits, anrag_candidate *d_out);
