@@ -205,6 +205,13 @@ struct WaveTopK {
         S ss = flag ? cs : neg_inf<S>();
         uint32_t sr = flag ? cr : kNoRow;
         bitonic_sort64(ss, sr);
+        if (read_lane(r, 0) == kNoRow) {  // empty list (its best slot is): the sorted candidates ARE the new list
+            s = ss;
+            r = sr;
+            thr_s = read_lane(s, k - 1);
+            thr_r = read_lane(r, k - 1);
+            return;
+        }
         merge_reversed(lane_reverse(ss), lane_reverse(sr));
     }
 
