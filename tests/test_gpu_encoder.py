@@ -31,3 +31,22 @@ def test_text_query_end_to_end():
     full = emb @ q
     assert r.index.tolist() == np.lexsort((np.arange(len(docs)), -full))[:5].tolist() or \
         np.max(np.abs(np.sort(full)[::-1][:5] - r["similarity"].to_numpy())) < 1e-4
+
+
+def test_query_graph_replay_matches_eager():
+    """`encode_query` replays a captured hipGraph per token-length bucket; the result must be the eager forward's up
+    to fp16 noise (the bucket pads the sequence; padded positions are masked), for queries of several lengths and
+    when the same bucket is reused."""
+    from anrag.encoder import LocalEncoder
+
+    enc = LocalEncoder()
+    texts = ["asthma", "what dose of inhaled corticosteroid for adults with asthma and chronic kidney disease",
+             " ".join(["hypertension treatment threshold"] * 20), "stroke rehabilitation at home"]
+    enc.use_graphs = False
+    eager = np.stack([enc.encode_query(t) for t in texts])
+    enc.use_graphs = True
+    replay = np.stack([enc.encode_query(t) for t in texts])
+    again = np.stack([enc.encode_query(t) for t in texts])
+    assert any(v is not None for v in enc._graphs.values()), "graph capture did not happen on this build"
+    assert np.max(np.abs(replay - eager)) < 3e-3 and np.array_equal(replay, again)
+    assert np.allclose(np.linalg.norm(replay, axis=1), 1.0, atol=1e-3)
