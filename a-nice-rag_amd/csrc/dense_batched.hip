@@ -289,8 +289,7 @@ void free_batched(anrag_index *idx) {
 }
 
 template <int QW>
-static int batched_passes(anrag_index *idx, hipStream_t st, int32_t nq, int32_t k, int64_t n_sample, int64_t stride,
-                          const uint32_t *allow, Cand32 *cand) {
+static int batched_attrs() {
     using Geo = BatchGeom<QW>;
     static bool attr_set = false;
     if (!attr_set) {
@@ -304,30 +303,48 @@ static int batched_passes(anrag_index *idx, hipStream_t st, int32_t nq, int32_t 
                                       hipFuncAttributeMaxDynamicSharedMemorySize, Geo::kLdsBytes));
         attr_set = true;
     }
+    return ANRAG_OK;
+}
+
+// workgroups for a pass over `rows` corpus rows in geometry QW: one per tile and query block, capped at what the
+// chip holds at 8 waves per CU
+template <int QW>
+static unsigned batched_grid(const anrag_index *idx, int64_t rows, int n_qblocks) {
+    const int wg_per_cu = 512 / BatchGeom<QW>::kThreads;
+    const int64_t tiles = (rows + kBM - 1) / kBM;
+    const int64_t per_block = (int64_t)wg_per_cu * idx->n_cus / n_qblocks;
+    return (unsigned)((tiles < per_block ? tiles : per_block) * n_qblocks);
+}
+
+template <int QW>
+static int batched_passes(anrag_index *idx, hipStream_t st, int32_t nq, int32_t k, int64_t n_sample, int64_t stride,
+                          const uint32_t *allow, Cand32 *cand) {
+    using Geo = BatchGeom<QW>;
+    using GeoS = BatchGeom<128>;
+    int rc;
+    if ((rc = batched_attrs<QW>()) || (rc = batched_attrs<128>())) return rc;
     const int64_t n = idx->n_rows;
     const int dim = idx->dim;
     const int n_qblocks = (nq + QW - 1) / QW;  // 1
-    const int wg_per_cu = 512 / Geo::kThreads;  // 8 waves per CU either way
-    auto grid_for = [&](int64_t rows) {
-        const int64_t tiles = (rows + kBM - 1) / kBM;
-        const int64_t per_block = (int64_t)wg_per_cu * idx->n_cus / n_qblocks;
-        return (unsigned)((tiles < per_block ? tiles : per_block) * n_qblocks);
-    };
+    // The sampled pass is a few thousand rows = a few dozen tiles: its duration is ONE tile's latency, whatever the
+    // geometry's throughput.  It always runs in the 128-query geometry (half the matrix work per workgroup and
+    // k-step, one wave per SIMD): ~50 us instead of ~100 us for 256 queries.
+    const int sq = (nq + 127) / 128;
     if (allow)
-        dense_batched_kernel<QW, true, true><<<grid_for(n_sample), Geo::kThreads, Geo::kLdsBytes, st>>>(
-            idx->d_emb, idx->d_bq, n_qblocks, n, dim, nq, n_sample, stride, nullptr, idx->d_bsample, nullptr, nullptr, 0,
+        dense_batched_kernel<128, true, true><<<batched_grid<128>(idx, n_sample, sq), GeoS::kThreads, GeoS::kLdsBytes, st>>>(
+            idx->d_emb, idx->d_bq, sq, n, dim, nq, n_sample, stride, nullptr, idx->d_bsample, nullptr, nullptr, 0,
             idx->d_dense_src, allow);
     else
-        dense_batched_kernel<QW, true, false><<<grid_for(n_sample), Geo::kThreads, Geo::kLdsBytes, st>>>(
-            idx->d_emb, idx->d_bq, n_qblocks, n, dim, nq, n_sample, stride, nullptr, idx->d_bsample, nullptr, nullptr, 0,
+        dense_batched_kernel<128, true, false><<<batched_grid<128>(idx, n_sample, sq), GeoS::kThreads, GeoS::kLdsBytes, st>>>(
+            idx->d_emb, idx->d_bq, sq, n, dim, nq, n_sample, stride, nullptr, idx->d_bsample, nullptr, nullptr, 0,
             nullptr, nullptr);
     batched_threshold_kernel<<<nq, 64, 0, st>>>(idx->d_bsample, n_sample, k, idx->d_btau, idx->d_bcnt);
     if (allow)
-        dense_batched_kernel<QW, false, true><<<grid_for(n), Geo::kThreads, Geo::kLdsBytes, st>>>(
+        dense_batched_kernel<QW, false, true><<<batched_grid<QW>(idx, n, n_qblocks), Geo::kThreads, Geo::kLdsBytes, st>>>(
             idx->d_emb, idx->d_bq, n_qblocks, n, dim, nq, n, 1, idx->d_btau, nullptr, idx->d_bcnt, cand, kCandCap,
             idx->d_dense_src, allow);
     else
-        dense_batched_kernel<QW, false, false><<<grid_for(n), Geo::kThreads, Geo::kLdsBytes, st>>>(
+        dense_batched_kernel<QW, false, false><<<batched_grid<QW>(idx, n, n_qblocks), Geo::kThreads, Geo::kLdsBytes, st>>>(
             idx->d_emb, idx->d_bq, n_qblocks, n, dim, nq, n, 1, idx->d_btau, nullptr, idx->d_bcnt, cand, kCandCap, nullptr,
             nullptr);
     ANRAG_HIP(hipGetLastError());
