@@ -2,7 +2,7 @@
 """Is the per-query floor host enqueue time or device chain time?  python scripts/host_vs_device.py [rows]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np, torch
+import torch
 from anrag import synth, _native as nat
 from anrag.index import Index
 rows = int(sys.argv[1]) if len(sys.argv) > 1 else 20000

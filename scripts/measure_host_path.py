@@ -3,7 +3,7 @@
 one host sync per query) on the same 1M x 768 hybrid workload as bench.py.  Not the headline number."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np, torch
+import torch
 from anrag import synth
 from anrag.index import Index
 

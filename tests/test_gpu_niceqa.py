@@ -4,7 +4,6 @@ identical (the stand-in embeddings are sparse hashed BoW: exact dense ties are p
 uses the same (score desc, row asc) rule)."""
 import os
 
-import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu

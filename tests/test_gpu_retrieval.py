@@ -1,7 +1,6 @@
 """GPU: the reference-shaped host layer (DatabaseManager / SearchEngine / RetrievalEvaluationSystem) end to end
 over real SQLite `chunks` DBs and a BM25 pickle, against the ids the REFERENCE's own retrieve_documents returned
 (tests/golden/ref_end_to_end.json) -- through both routes: method-by-method and the fused single ABI call."""
-import os
 import pickle
 import sqlite3
 
