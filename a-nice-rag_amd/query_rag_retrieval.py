@@ -130,6 +130,16 @@ class RetrievalEvaluationSystem:
                 if ids is not None:
                     return ids
 
+            # ---- ids-only route for everything else that returns ids and does not rerank (retrieval_eval's
+            # full-ranking configurations: k = 12000, several dense models): the same legs and the same fusion as
+            # below, but on row numbers -- no result frames, no per-row dicts, ids mapped to strings at the end
+            if self.fused and not return_docs and not will_rerank:
+                ids = self._rank_route(source_enum, active, query_embeddings, query_tokens, query_text, want_bm25,
+                                       bm25, bm25_sections, bm25_section_ids, similarity_k, common_sections_n,
+                                       model_weights, filename_type_filter, wrrf_k)
+                if ids is not None:
+                    return ids
+
             ranked_lists = []
             all_results: Dict[str, dict] = {}
             for key, df in active:
@@ -185,6 +195,59 @@ class RetrievalEvaluationSystem:
                 raise
             logger.error(f"Error in retrieval processing: {e}")
             return []
+
+    # ------------------------------------------------------------------ ids-only route
+    def _gids(self, source_enum, owner_key, id_strings) -> np.ndarray:
+        """Chunk-id strings of one frame / of the BM25 sections as integers of one table per info source (built
+        once per frame: the frames live as long as the system)."""
+        tables = self.__dict__.setdefault("_gid_tables", {})
+        t = tables.setdefault(source_enum, {"of": {}, "names": [], "arrays": {}})
+        arr = t["arrays"].get(owner_key)
+        if arr is not None:
+            return arr
+        import threading
+
+        with self.__dict__.setdefault("_gid_lock", threading.Lock()):  # one writer: an id gets ONE integer
+            arr = t["arrays"].get(owner_key)
+            if arr is not None:
+                return arr
+            of, names = t["of"], t["names"]
+            arr = np.empty(len(id_strings), dtype=np.int64)
+            for i, cid in enumerate(id_strings):
+                g = of.get(cid)
+                if g is None:
+                    g = of[cid] = len(names)
+                    names.append(cid)
+                arr[i] = g
+            t["arrays"][owner_key] = arr
+            return arr
+
+    def _rank_route(self, source_enum, active, query_embeddings, query_tokens, query_text, want_bm25, bm25,
+                    bm25_sections, bm25_section_ids, similarity_k, common_sections_n, model_weights,
+                    filename_type_filter, wrrf_k) -> Optional[List[str]]:
+        se = self.search_engine
+        lists, weights = [], []
+        for key, df in active:
+            rows = se.dense_rows(query_embeddings[key], df, key, similarity_k, filename_type_filter)
+            if rows is not None and len(rows):
+                lists.append(self._gids(source_enum, ("dense", id(df)), df["id"].tolist())[rows])
+                weights.append(model_weights.get(key, 1.0))
+        if want_bm25:
+            if query_tokens or query_text:
+                rows = se.bm25_rows(query_tokens, query_text, bm25, bm25_sections, similarity_k, filename_type_filter)
+                if rows is not None and len(rows):
+                    lists.append(self._gids(source_enum, ("bm25", id(bm25_section_ids)), bm25_section_ids)[rows])
+                    weights.append(model_weights.get("BM25", 1.0))
+            else:
+                logger.warning("BM25 search requested but no query_text or query_tokens provided - skipping BM25")
+        if not lists:
+            return []
+        if len(lists) > 1:
+            gids = se.fuse_rows(lists, weights, wrrf_k, common_sections_n)
+        else:
+            gids = lists[0][:common_sections_n]
+        names = self._gid_tables[source_enum]["names"]
+        return [names[g] for g in gids.tolist()]
 
     def retrieve_documents_batch(self, queries: List[Dict], **params) -> List[List[str]]:
         """`retrieve_documents` for a LIST of queries (no reference counterpart: retrieval_eval.py:51-84 loops).

@@ -264,6 +264,53 @@ class SearchEngine:
         doc, _, count = proxy.index.bm25_search(proxy.term_ids(query_tokens), int(similarity_k), allow)
         return [bm25_section_ids[i] for i in doc[:count].tolist()]
 
+    # ------------------------------------------------------------------ row-level legs (ids-only routes)
+    def dense_rows(self, query_embedding: np.ndarray, df: pd.DataFrame, model_name: str, similarity_k: int,
+                   filename_type_filter: Optional[str]) -> Optional[np.ndarray]:
+        """The ranking `similarity_search_with_embedding` returns, as DataFrame POSITIONS and without building the
+        result frame (a 9,609-row frame + `to_dict("records")` per query is ~20 ms of pandas; the search is < 1 ms).
+        None = what the method would have answered with an empty frame (nothing left after the filter, or an
+        error, logged as there)."""
+        try:
+            if df.empty:
+                return None
+            _, rows, _ = self._dense_topk(query_embedding, df, similarity_k, filename_type_filter)
+            return rows
+        except AnragError as e:
+            if e.code in _FATAL:
+                raise
+            self.logger.error(f"Error in {model_name} similarity search with precalculated embedding: {e}")
+            return None
+        except Exception as e:
+            self.logger.error(f"Error in {model_name} similarity search with precalculated embedding: {e}")
+            return None
+
+    def bm25_rows(self, query_tokens: Optional[List[str]], query_text: Optional[str], bm25, bm25_sections,
+                  similarity_k: int, filename_type_filter: Optional[str]) -> Optional[np.ndarray]:
+        """`bm25_search_preprocessed` (tokens given) / `bm25_search` (text, lemmatised) as section POSITIONS."""
+        try:
+            if not query_tokens:
+                query_tokens = preprocess_text(query_text, use_lemmatization=True)
+            if not query_tokens:
+                return None
+            proxy = self._proxy(bm25, bm25_sections)
+            allow = _allow_of(proxy, "bm25", filename_type_filter) if filename_type_filter else None
+            doc, _, count = proxy.index.bm25_search(proxy.term_ids(query_tokens), int(similarity_k), allow)
+            return doc[:count]
+        except AnragError as e:
+            if e.code in _FATAL:
+                raise
+            self.logger.error(f"Error in BM25 search: {e}")
+            return None
+        except Exception as e:
+            self.logger.error(f"Error in BM25 search: {e}")
+            return None
+
+    def fuse_rows(self, lists: Sequence[np.ndarray], weights: Sequence[float], k, top_n: int) -> np.ndarray:
+        """Weighted RRF over integer id lists (`anrag_wrrf`), first `top_n` fused ids."""
+        ids, _ = self._utility_index().wrrf([np.asarray(l, dtype=np.int64) for l in lists], list(weights), k, int(top_n))
+        return ids
+
     def bm25_search(self, query_text: str, bm25, bm25_sections, bm25_section_ids, similarity_k: int = 25,
                     filename_type_filter: Optional[str] = None, use_lemmatized: bool = True) -> List[str]:
         """search_engine.py:245-269."""
