@@ -222,8 +222,8 @@ int anrag_hybrid_search(anrag_index *idx, const float *query, const int32_t *ter
  * Back-to-back queries pipeline: the scans stay adjacent on the primary stream;
  * BM25 and the tail of query i run under the scans of the following queries.
  * Three launches per query: K1, K3 and one tail kernel (list merges + WRRF).
- * At most 8 queries are in flight per index: the call blocks on the HOST (never
- * on the device) until the query 8 back has finished with its buffers. */
+ * At most 16 queries are in flight per index: the call blocks on the HOST (never
+ * on the device) until the query 16 back has finished with its buffers. */
 int anrag_hybrid_search_device(anrag_index *idx, const float *d_query, const int32_t *d_term_ids,
                                int32_t n_terms, int32_t similarity_k, double w_dense,
                                double w_bm25, double wrrf_k, int32_t top_n,
