@@ -334,8 +334,9 @@ struct GroupQuery {
 static int hybrid_enqueue_group(anrag_index *idx, TailMode tail, const GroupQuery *q, int32_t n, int32_t k,
                                 double w_dense, double w_bm25, double wrrf_k, int32_t top_n,
                                 const uint32_t *d_allow_dense, const uint32_t *d_allow_bm25);
-constexpr int kScanGroup = 4;  // queries per scan launch when a call brings several (measured: 1 -> 4 queries per
-                               // launch = +14 % at 100k rows, +10 % at 125k rows, nothing at 1M rows; 8 is worse)
+constexpr int kScanGroup = 8;  // queries per scan launch when a call brings several (measured, queries per launch
+                               // 1 -> 4 -> 8: 53.6 -> 47.1 -> 45.7 us per query at 100k rows, 64.0 -> 57.9 us at 125k
+                               // rows for 4, nothing at 1M rows)
 
 int anrag_dense_search_device(anrag_index *idx, const float *d_queries, int32_t n_queries, int32_t k,
                               const uint32_t *d_allow_bits, anrag_candidate *d_out) {

@@ -19,8 +19,8 @@ constexpr int kListLen = 64;         // one top-k slot per lane (ANRAG_FUSED_K_M
 constexpr int kScanThreads = 256;    // 4 waves: one scan workgroup per CU (sweep: profiles/r01_scan_config_sweep.txt)
 constexpr int kScanWaves = kScanThreads / kWave;
 constexpr int kScanGroupMax = 8;   // queries one scan launch can carry (dense_scan.hip)
-constexpr int kPipeSlots = 16;     // queries in flight in the hybrid pipeline (list sets, events): four exchange
-                                   // groups of 4, so a slow collective on the communication stream (which the tails
+constexpr int kPipeSlots = 32;     // queries in flight in the hybrid pipeline (list sets, events): four exchange
+                                   // groups of 8, so a slow collective on the communication stream (which the tails
                                    // queue behind) does not stall the scans two groups later
 constexpr int kMaxScanBlocks = 256;  // one per CU; also bounds the final merge fan-in
 constexpr uint32_t kNoRow = 0xFFFFFFFFu;

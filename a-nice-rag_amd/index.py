@@ -248,7 +248,7 @@ class Index:
         return ms.value, n.value
 
     def profile_units(self, kernel_id: int) -> int:
-        """Queries the timed launches of a kernel carried (K1 launches carry up to 4 for query groups)."""
+        """Queries the timed launches of a kernel carried (K1 launches carry up to 8 for query groups)."""
         n = C.c_int64(0)
         nat.check(self._lib.anrag_profile_read_units(self.handle, int(kernel_id), C.byref(n)))
         return n.value

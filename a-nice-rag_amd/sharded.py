@@ -7,7 +7,7 @@ The reference has no distributed code at all; this is the 
 Per query, on every rank:
     1. local legs          K1 dense scan + K3 BM25 on the rank's rows, tail kernel -> 2k candidate records
                            (`anrag_hybrid_candidates_group_device`: scans on the compute stream -- the queries of
-                           an exchange group share scan launches, 4 per launch, each still its own pass --, BM25
+                           an exchange group share scan launches, 8 per launch, each still its own pass --, BM25
                            on the index's second stream, tail + copy-out on the communication stream)
     2. exchange            all-gather of the candidate records -- 2k x 16 B per query and rank (k=25: 800 B):
                            latency-bound, nowhere near the 7 x 153 GB/s xGMI links.  It runs on a separate

@@ -49,7 +49,7 @@ def parse_args():
     ap.add_argument("--batch", type=int, default=256, help="queries per pass of --workload batched")
     ap.add_argument("--batch-precision", choices=["f32", "bf16x3"], default="f32",
                     help="--workload batched: exact f32 MFMA (default) or opt-in split-precision bf16 x 3 products")
-    ap.add_argument("--exchange-group", type=int, default=4,
+    ap.add_argument("--exchange-group", type=int, default=8,
                     help="N > 1: in-flight queries that share one all-gather (each is still scanned alone)")
     ap.add_argument("--filter", action="store_true",
                     help="single-GPU diagnostic: source-prefix filter as retrieval_eval.py:280 passes it ('CG,NG'); rows "

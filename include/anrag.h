@@ -132,7 +132,7 @@ int anrag_dense_search(anrag_index *idx, const float *queries, int32_t n_queries
  * anrag_candidate.  The scans run back to back on the primary stream, each
  * query's list merge on the fusion stream under the next scan: results are
  * complete in fusion-stream order (anrag_index_sync waits for everything).
- * n_queries > 1: up to 4 queries share a scan launch (each is still its own pass
+ * n_queries > 1: up to 8 queries share a scan launch (each is still its own pass
  * over the matrix; a workgroup starts the next query when it has finished this one).
  * d_allow_bits: nullable device bitmap, bit s of word s/32 = source s allowed. */
 int anrag_dense_search_device(anrag_index *idx, const float *d_queries, int32_t n_queries,
@@ -222,8 +222,8 @@ int anrag_hybrid_search(anrag_index *idx, const float *query, const int32_t *ter
  * Back-to-back queries pipeline: the scans stay adjacent on the primary stream;
  * BM25 and the tail of query i run under the scans of the following queries.
  * Three launches per query: K1, K3 and one tail kernel (list merges + WRRF).
- * At most 16 queries are in flight per index: the call blocks on the HOST (never
- * on the device) until the query 16 back has finished with its buffers. */
+ * At most 32 queries are in flight per index: the call blocks on the HOST (never
+ * on the device) until the query 32 back has finished with its buffers. */
 int anrag_hybrid_search_device(anrag_index *idx, const float *d_query, const int32_t *d_term_ids,
                                int32_t n_terms, int32_t similarity_k, double w_dense,
                                double w_bm25, double wrrf_k, int32_t top_n,
@@ -267,7 +267,7 @@ int anrag_hybrid_candidates_device(anrag_index *idx, const float *d_query,
 
 /* The same for n_queries queries in one call: d_queries / d_term_ids / d_out are HOST
  * arrays of device pointers, n_terms a host array.  The library scans the queries in
- * groups of 4 per launch (each query still its own pass over the shard) -- at the
+ * groups of 8 per launch (each query still its own pass over the shard) -- at the
  * shard sizes of 8 GPUs that is worth 10-14 % over n single calls.  What the sharded
  * searcher calls once per exchange group. */
 int anrag_hybrid_candidates_group_device(anrag_index *idx, const float *const *d_queries,
@@ -315,7 +315,7 @@ int anrag_profile_enable(anrag_index *idx, uint32_t kernel_mask);
 int anrag_profile_set_sampling(anrag_index *idx, int32_t every_n);
 int anrag_profile_reset(anrag_index *idx);
 int anrag_profile_read(anrag_index *idx, int kernel_id, double *out_total_ms, int64_t *out_launches);
-/* Queries the timed launches of a kernel carried (a K1 launch carries up to 4 when the
+/* Queries the timed launches of a kernel carried (a K1 launch carries up to 8 when the
  * caller submits query groups): algorithmic bytes per launch = units / launches x N*D*4. */
 int anrag_profile_read_units(anrag_index *idx, int kernel_id, int64_t *out_units);
 /* Shape facts a caller needs for roofline arithmetic. */
