@@ -202,7 +202,8 @@ def main():
     main_kernel = nat.KERNEL_DENSE_BATCHED if batched else nat.KERNEL_DENSE_SCAN
     # HIP events around the dominant kernel, on every 8th launch: a bracket holds its stream for ~10 us, which
     # at batch=1 would be charged to every query (measured: 463 -> 452 us/step at 1M rows)
-    idx.profile(True, kernels=[main_kernel], every=1 if batched else 8)
+    # (a sharded K1 launch carries a whole exchange group: every 2nd launch is sample enough and cheap enough)
+    idx.profile(True, kernels=[main_kernel], every=1 if batched else (2 if sharded else 8))
     idx.profile_reset()
     barrier()
     t0 = time.perf_counter()
@@ -212,7 +213,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     scan_ms, scan_n = idx.profile_read(main_kernel)
-    scan_units = idx.profile_units(main_kernel)  # queries the timed launches carried (sharded: 4 per K1 launch)
+    scan_units = idx.profile_units(main_kernel)  # queries the timed launches carried (sharded: one exchange group per K1 launch)
     idx.profile(False)
     if world > 1:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
