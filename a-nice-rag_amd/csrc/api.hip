@@ -780,11 +780,11 @@ static constexpr size_t kSlotTerms = 4096 * sizeof(int32_t), kSlotAllow = 2048 *
                         kSlotOut = 2 * ANRAG_FUSED_K_MAX * sizeof(anrag_candidate);
 
 static void free_host_slots(anrag_index *idx) {
+    if (idx->host_slots_h) (void)hipHostFree(idx->host_slots_h);
+    if (idx->host_slots_d) (void)hipFree(idx->host_slots_d);
+    idx->host_slots_h = nullptr;
+    idx->host_slots_d = nullptr;
     for (auto &hs : idx->host_slot) {
-        if (hs.h) (void)hipHostFree(hs.h);
-        for (void *p : {(void *)hs.d_query, (void *)hs.d_terms, (void *)hs.d_allow_a, (void *)hs.d_allow_b,
-                        (void *)hs.d_out, (void *)hs.d_count})
-            if (p) (void)hipFree(p);
         if (hs.done) (void)hipEventDestroy(hs.done);
         hs = anrag_index::HostSlot();
     }
@@ -802,16 +802,22 @@ static int ensure_host_slots(anrag_index *idx, std::unique_lock<std::mutex> &loc
     });
     if (idx->host_slot_dim == dim) return ANRAG_OK;  // another caller did it while this one waited
     free_host_slots(idx);
+    // ONE pinned block and ONE device block, carved per slot: query | terms | allow (dense) | allow (BM25) |
+    // result records | count
     const size_t qbytes = ((size_t)dim * sizeof(float) + 255) / 256 * 256;
-    for (auto &hs : idx->host_slot) {
-        ANRAG_HIP(hipHostMalloc(reinterpret_cast<void **>(&hs.h), qbytes + kSlotTerms + 2 * kSlotAllow + kSlotOut + 256,
-                                hipHostMallocDefault));
-        ANRAG_HIP(hipMalloc(reinterpret_cast<void **>(&hs.d_query), qbytes));
-        ANRAG_HIP(hipMalloc(reinterpret_cast<void **>(&hs.d_terms), kSlotTerms));
-        ANRAG_HIP(hipMalloc(reinterpret_cast<void **>(&hs.d_allow_a), kSlotAllow));
-        ANRAG_HIP(hipMalloc(reinterpret_cast<void **>(&hs.d_allow_b), kSlotAllow));
-        ANRAG_HIP(hipMalloc(reinterpret_cast<void **>(&hs.d_out), kSlotOut));
-        ANRAG_HIP(hipMalloc(reinterpret_cast<void **>(&hs.d_count), 256));
+    const size_t slot_bytes = qbytes + kSlotTerms + 2 * kSlotAllow + kSlotOut + 256;
+    ANRAG_HIP(hipHostMalloc(reinterpret_cast<void **>(&idx->host_slots_h), slot_bytes * kPipeSlots, hipHostMallocDefault));
+    ANRAG_HIP(hipMalloc(reinterpret_cast<void **>(&idx->host_slots_d), slot_bytes * kPipeSlots));
+    for (int i = 0; i < kPipeSlots; ++i) {
+        anrag_index::HostSlot &hs = idx->host_slot[i];
+        hs.h = idx->host_slots_h + (size_t)i * slot_bytes;
+        char *d = idx->host_slots_d + (size_t)i * slot_bytes;
+        hs.d_query = reinterpret_cast<float *>(d);
+        hs.d_terms = reinterpret_cast<int32_t *>(d + qbytes);
+        hs.d_allow_a = reinterpret_cast<uint32_t *>(d + qbytes + kSlotTerms);
+        hs.d_allow_b = reinterpret_cast<uint32_t *>(d + qbytes + kSlotTerms + kSlotAllow);
+        hs.d_out = reinterpret_cast<anrag_candidate *>(d + qbytes + kSlotTerms + 2 * kSlotAllow);
+        hs.d_count = reinterpret_cast<int32_t *>(d + qbytes + kSlotTerms + 2 * kSlotAllow + kSlotOut);
         ANRAG_HIP(hipEventCreateWithFlags(&hs.done, hipEventDisableTiming));
     }
     idx->host_slot_dim = dim;

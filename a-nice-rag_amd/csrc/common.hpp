@@ -82,6 +82,7 @@ struct anrag_index {
         bool busy = false;
     };
     HostSlot host_slot[anrag::kPipeSlots];
+    char *host_slots_h = nullptr, *host_slots_d = nullptr;  // the one pinned / one device block the slots carve
     int32_t host_slot_dim = 0;        // dim the slots were sized for (0: not allocated)
     std::condition_variable slot_cv;
 
