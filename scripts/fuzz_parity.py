@@ -21,78 +21,82 @@ def log(*a):
     print(*a, file=LOG, flush=True)
 
 
-budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
-seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
-rng = np.random.default_rng(seed)
-t_end = time.time() + budget
-rounds = checks = 0
-DIMS = [8, 24, 64, 128, 192, 256, 320, 384, 448, 512, 640, 768, 896, 1024, 1536, 2048]
-while time.time() < t_end:
-    rounds += 1
-    n = int(rng.choice([1, 2, 3, 17, 63, 64, 65, 255, 257, 1000, 4095, 4096, 4097, 9000, 20000]))
-    d = int(rng.choice(DIMS))
-    n_src = int(rng.integers(1, 12))
-    e = rng.standard_normal((n, d), dtype=np.float32)
-    if rng.random() < 0.3:  # exact ties: duplicated rows
-        e[rng.integers(0, n, size=max(1, n // 4))] = e[0]
-    e /= np.maximum(np.linalg.norm(e, axis=1, keepdims=True), 1e-12)
-    sid = rng.integers(0, n_src, size=n).astype(np.uint16)
-    vocab = int(rng.choice([5, 50, 2000]))
-    lens = rng.integers(0, 40, size=n)
-    zipf = rng.zipf(1.3, size=int(lens.sum())) % vocab
-    corpus, at = [], 0
-    for L in lens:
-        corpus.append([str(t) for t in zipf[at: at + L]])
-        at += L
-    if not any(corpus):
-        corpus[0] = ["0"]
-    log("corpus", rounds, "n", n, "d", d, "n_src", n_src, "vocab", vocab, "postings", int(lens.sum()))
-    ref = BM25Okapi(corpus, k1=1.7, b=0.83, epsilon=0.05)
-    bi = Bm25Index(corpus, k1=1.7, b=0.83, epsilon=0.05)
-    with Index(0) as idx:
-        idx.dense_load(e, source_id=sid)
-        idx.bm25_load(bi.indptr, bi.post_doc, bi.post_tf, bi.idf, bi.doc_len, bi.avgdl, bi.k1, bi.b, source_id=sid)
-        for trial in range(6):
-            k = int(rng.choice([1, 2, 10, 25, 63, 64, 65, 100, n + 3]))
-            allow = None if rng.random() < 0.5 else (rng.random(n_src) < 0.6).astype(np.uint8)
-            mask = None if allow is None else allow[sid].astype(bool)
-            q = e[int(rng.integers(n))] + 0.1 * rng.standard_normal(d).astype(np.float32)
-            log("  trial", trial, "k", k, "filter", allow is not None)
-            # dense
-            doc, score, cnt = idx.dense_search(q, k, allow)
-            log("   dense ok")
-            sims = ref_search.dense_scores(q, e)
-            want_n = min(k, n if mask is None else int(mask.sum()))
-            assert int(cnt[0]) == want_n, ("dense count", n, d, k, int(cnt[0]), want_n)
-            if want_n:
-                rr = ref_search.canonical_topk(sims, k, mask)
-                assert_ranking_matches(rr, sims[rr], doc[0, :want_n], score[0, :want_n], 1e-4, sims,
-                                       f"dense n={n} d={d} k={k}")
-            # BM25: exact
-            nt = int(rng.integers(0, 12))
-            toks = [str(t) for t in rng.integers(0, vocab + 3, size=nt)]
-            if nt and rng.random() < 0.3:
-                toks.append(toks[0])
-            tid = bi.term_ids(toks)
-            log("   bm25", toks)
-            bdoc, bscore, bcnt = idx.bm25_search(tid, k, allow)
-            log("   bm25 ok")
-            sc = ref.get_scores(toks) if toks else np.zeros(n)
-            rows = ref_search.canonical_topk(sc, k, mask)
-            if toks:
-                assert bdoc[:bcnt].tolist() == rows.tolist(), ("bm25 ids", n, vocab, k, toks)
-                assert bscore[:bcnt].tolist() == sc[rows].tolist(), ("bm25 scores", n, vocab, k)
-                assert np.array_equal(idx.bm25_scores(tid), sc), ("bm25 score vector", n, vocab)
-            # fused hybrid (k <= 64) from the device's dense ranking + exact BM25
-            if k <= 64 and toks:
-                top_n = int(rng.choice([1, 10, 15, 2 * k]))
-                log("   hybrid top_n", top_n)
-                hid, hs = idx.hybrid_search(q, tid, k, 5.0, 1.0, 40.0, top_n, allow, allow)
-                log("   hybrid ok")
-                dl = doc[0, :want_n].tolist()
-                bl = rows.tolist()
-                want = ref_search.weighted_reciprocal_rank_fusion([(dl, "d"), (bl, "b")], {"d": 5.0, "b": 1.0}, 40)[:top_n]
-                assert hid.tolist() == [i for i, _ in want], ("hybrid ids", n, d, k, top_n)
-                assert hs.tolist() == [s for _, s in want], ("hybrid scores", n, d, k)
-            checks += 1
-print(f"fuzz ok: {rounds} corpora, {checks} query checks in {budget:.0f} s (seed {seed})")
+def run(budget: float = 60.0, seed: int = 0) -> int:
+    rng = np.random.default_rng(seed)
+    t_end = time.time() + budget
+    rounds = checks = 0
+    DIMS = [8, 24, 64, 128, 192, 256, 320, 384, 448, 512, 640, 768, 896, 1024, 1536, 2048]
+    while time.time() < t_end:
+        rounds += 1
+        n = int(rng.choice([1, 2, 3, 17, 63, 64, 65, 255, 257, 1000, 4095, 4096, 4097, 9000, 20000]))
+        d = int(rng.choice(DIMS))
+        n_src = int(rng.integers(1, 12))
+        e = rng.standard_normal((n, d), dtype=np.float32)
+        if rng.random() < 0.3:  # exact ties: duplicated rows
+            e[rng.integers(0, n, size=max(1, n // 4))] = e[0]
+        e /= np.maximum(np.linalg.norm(e, axis=1, keepdims=True), 1e-12)
+        sid = rng.integers(0, n_src, size=n).astype(np.uint16)
+        vocab = int(rng.choice([5, 50, 2000]))
+        lens = rng.integers(0, 40, size=n)
+        zipf = rng.zipf(1.3, size=int(lens.sum())) % vocab
+        corpus, at = [], 0
+        for L in lens:
+            corpus.append([str(t) for t in zipf[at: at + L]])
+            at += L
+        if not any(corpus):
+            corpus[0] = ["0"]
+        log("corpus", rounds, "n", n, "d", d, "n_src", n_src, "vocab", vocab, "postings", int(lens.sum()))
+        ref = BM25Okapi(corpus, k1=1.7, b=0.83, epsilon=0.05)
+        bi = Bm25Index(corpus, k1=1.7, b=0.83, epsilon=0.05)
+        with Index(0) as idx:
+            idx.dense_load(e, source_id=sid)
+            idx.bm25_load(bi.indptr, bi.post_doc, bi.post_tf, bi.idf, bi.doc_len, bi.avgdl, bi.k1, bi.b, source_id=sid)
+            for trial in range(6):
+                k = int(rng.choice([1, 2, 10, 25, 63, 64, 65, 100, n + 3]))
+                allow = None if rng.random() < 0.5 else (rng.random(n_src) < 0.6).astype(np.uint8)
+                mask = None if allow is None else allow[sid].astype(bool)
+                q = e[int(rng.integers(n))] + 0.1 * rng.standard_normal(d).astype(np.float32)
+                log("  trial", trial, "k", k, "filter", allow is not None)
+                # dense
+                doc, score, cnt = idx.dense_search(q, k, allow)
+                log("   dense ok")
+                sims = ref_search.dense_scores(q, e)
+                want_n = min(k, n if mask is None else int(mask.sum()))
+                assert int(cnt[0]) == want_n, ("dense count", n, d, k, int(cnt[0]), want_n)
+                if want_n:
+                    rr = ref_search.canonical_topk(sims, k, mask)
+                    assert_ranking_matches(rr, sims[rr], doc[0, :want_n], score[0, :want_n], 1e-4, sims,
+                                           f"dense n={n} d={d} k={k}")
+                # BM25: exact
+                nt = int(rng.integers(0, 12))
+                toks = [str(t) for t in rng.integers(0, vocab + 3, size=nt)]
+                if nt and rng.random() < 0.3:
+                    toks.append(toks[0])
+                tid = bi.term_ids(toks)
+                log("   bm25", toks)
+                bdoc, bscore, bcnt = idx.bm25_search(tid, k, allow)
+                log("   bm25 ok")
+                sc = ref.get_scores(toks) if toks else np.zeros(n)
+                rows = ref_search.canonical_topk(sc, k, mask)
+                if toks:
+                    assert bdoc[:bcnt].tolist() == rows.tolist(), ("bm25 ids", n, vocab, k, toks)
+                    assert bscore[:bcnt].tolist() == sc[rows].tolist(), ("bm25 scores", n, vocab, k)
+                    assert np.array_equal(idx.bm25_scores(tid), sc), ("bm25 score vector", n, vocab)
+                # fused hybrid (k <= 64) from the device's dense ranking + exact BM25
+                if k <= 64 and toks:
+                    top_n = int(rng.choice([1, 10, 15, 2 * k]))
+                    log("   hybrid top_n", top_n)
+                    hid, hs = idx.hybrid_search(q, tid, k, 5.0, 1.0, 40.0, top_n, allow, allow)
+                    log("   hybrid ok")
+                    dl = doc[0, :want_n].tolist()
+                    bl = rows.tolist()
+                    want = ref_search.weighted_reciprocal_rank_fusion([(dl, "d"), (bl, "b")], {"d": 5.0, "b": 1.0}, 40)[:top_n]
+                    assert hid.tolist() == [i for i, _ in want], ("hybrid ids", n, d, k, top_n)
+                    assert hs.tolist() == [s for _, s in want], ("hybrid scores", n, d, k)
+                checks += 1
+    print(f"fuzz ok: {rounds} corpora, {checks} query checks in {budget:.0f} s (seed {seed})")
+    return checks
+
+
+if __name__ == "__main__":
+    run(float(sys.argv[1]) if len(sys.argv) > 1 else 60.0, int(sys.argv[2]) if len(sys.argv) > 2 else 0)

@@ -1,0 +1,18 @@
+"""GPU: a short, seeded run of the randomised differential check (scripts/fuzz_parity.py): random corpus shapes
+(1 .. 20,000 rows, 16 dimensions incl. the generic-kernel ones, exact duplicate rows), k below / at / above the
+fused limit and above N, source filters, duplicate / unknown / empty term lists -- dense within 1e-4 of the
+oracle, BM25 ids, scores and score vectors bit-exact, fused results bit-exact."""
+import importlib.util
+import os
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_seeded_fuzz_against_the_oracle():
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "fuzz_parity.py")
+    spec = importlib.util.spec_from_file_location("fuzz_parity", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.run(budget=12.0, seed=20260) > 200
