@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Randomised differential check of the HIP path against the oracle (test infrastructure, like tests/): random
-shapes, k, filters, duplicate / unknown / empty term lists, ties.  Dense: ids equal up to 1e-4 score ties; BM25 and
+shapes, k, filters, duplicate / unknown / empty term lists, ties, the list form against single calls.  Dense: ids equal
+up to 1e-4 score ties; BM25 and
 fusion: bit-exact.  usage: python scripts/fuzz_parity.py [seconds] [seed]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -94,6 +95,18 @@ def run(budget: float = 60.0, seed: int = 0) -> int:
                     assert hid.tolist() == [i for i, _ in want], ("hybrid ids", n, d, k, top_n)
                     assert hs.tolist() == [s for _, s in want], ("hybrid scores", n, d, k)
                 checks += 1
+            # the list form against the single calls (scan groups of 8, partial groups, a query without terms)
+            nb = int(rng.integers(1, 21))
+            qs = e[rng.integers(0, n, size=nb)] + 0.1 * rng.standard_normal((nb, d)).astype(np.float32)
+            tls = [bi.term_ids([str(t) for t in rng.integers(0, vocab + 2, size=int(rng.integers(0, 6)))]) for _ in range(nb)]
+            kb, tb = int(rng.choice([1, 10, 25, 64])), int(rng.choice([1, 10, 30]))
+            log("  batch", nb, kb, tb)
+            ids, scores, counts = idx.hybrid_search_batch(qs, tls, kb, 5.0, 1.0, 40.0, tb)
+            for i in range(nb):
+                wid, ws = idx.hybrid_search(qs[i], tls[i], kb, 5.0, 1.0, 40.0, tb)
+                c = int(counts[i])
+                assert c == len(wid) and ids[i, :c].tolist() == wid.tolist() and scores[i, :c].tolist() == ws.tolist(), \
+                    ("batch row", n, d, nb, i, kb, tb)
     print(f"fuzz ok: {rounds} corpora, {checks} query checks in {budget:.0f} s (seed {seed})")
     return checks
 
