@@ -61,12 +61,29 @@ class HipShardEngine:
         self._lib = index._lib
         self._nat = nat
 
-    def legs(self, d_query: torch.Tensor, d_terms: torch.Tensor, n_terms: int, k: int, out: torch.Tensor) -> None:
-        self._nat.check(self._lib.anrag_hybrid_candidates_device(
-            self.index.handle, d_query.data_ptr(), d_terms.data_ptr() if n_terms else None, n_terms, k, None, None,
-            out.data_ptr()))
+    def prepare_allow(self, allow_source) -> Optional[torch.Tensor]:
+        """Allow list (one byte per interned source id, as `Index.dense_search` takes it) -> the 2,048-word device
+        bitmap the device entry points take (bit s % 32 of word s / 32 = source s passes).  Source ids must mean
+        the same on every rank: intern the `source` strings globally when the shards are built."""
+        if allow_source is None:
+            return None
+        bits = np.zeros(65536, dtype=np.uint8)
+        a = np.asarray(allow_source, dtype=np.uint8)
+        bits[: a.size] = a != 0
+        return torch.from_numpy(np.packbits(bits, bitorder="little").view(np.int32).copy()).to(self.device)
 
-    def legs_group(self, queries, terms, n_terms, k: int, outs) -> None:
+    @staticmethod
+    def _ptr(t: Optional[torch.Tensor]):
+        return t.data_ptr() if t is not None else None
+
+    def legs(self, d_query: torch.Tensor, d_terms: torch.Tensor, n_terms: int, k: int, out: torch.Tensor,
+             allow_dense: Optional[torch.Tensor] = None, allow_bm25: Optional[torch.Tensor] = None) -> None:
+        self._nat.check(self._lib.anrag_hybrid_candidates_device(
+            self.index.handle, d_query.data_ptr(), d_terms.data_ptr() if n_terms else None, n_terms, k,
+            self._ptr(allow_dense), self._ptr(allow_bm25), out.data_ptr()))
+
+    def legs_group(self, queries, terms, n_terms, k: int, outs, allow_dense: Optional[torch.Tensor] = None,
+                   allow_bm25: Optional[torch.Tensor] = None) -> None:
         """`legs` for the queries of one exchange group in ONE library call: the shard is scanned once per query,
         but in a single launch per group of 4 (`anrag_hybrid_candidates_group_device`)."""
         import ctypes as C
@@ -74,8 +91,8 @@ class HipShardEngine:
         n = len(queries)
         ptrs = lambda ts: (C.c_void_p * n)(*[t.data_ptr() for t in ts])
         self._nat.check(self._lib.anrag_hybrid_candidates_group_device(
-            self.index.handle, ptrs(queries), ptrs(terms), (C.c_int32 * n)(*[int(x) for x in n_terms]), n, k, None, None,
-            ptrs(outs)))
+            self.index.handle, ptrs(queries), ptrs(terms), (C.c_int32 * n)(*[int(x) for x in n_terms]), n, k,
+            self._ptr(allow_dense), self._ptr(allow_bm25), ptrs(outs)))
 
     def merge_fuse(self, lists: torch.Tensor, n_lists: int, k: int, stride: int, w_dense: float, w_bm25: float,
                    wrrf_k: float, top_n: int, n_queries: int, out: torch.Tensor, count: torch.Tensor) -> None:
@@ -112,6 +129,16 @@ class ShardedSearcher:
         self._filled = 0
         self._grouped = self.group > 1 and hasattr(engine, "legs_group")
         self._pending: List[tuple] = []
+        self._allow = (None, None)  # engine-prepared source filters (dense rows, BM25 sections)
+        self._filtered = False
+
+    def set_filter(self, allow_dense=None, allow_bm25=None) -> None:
+        """Source filter for the queries submitted from now on (the reference passes `filename_type_filter` per
+        call, search_engine.py:36-55 / :221-231): allow lists over the interned source ids, one byte per id, None =
+        no filter.  Every rank must set the same filter at the same point; queries submitted before are flushed."""
+        self.flush()
+        self._allow = (self.engine.prepare_allow(allow_dense), self.engine.prepare_allow(allow_bm25))
+        self._filtered = allow_dense is not None or allow_bm25 is not None
 
     def submit(self, d_query: torch.Tensor, d_terms: torch.Tensor, n_terms: int) -> Tuple[int, int]:
         slot, g = self._slot, self._filled
@@ -121,8 +148,10 @@ class ShardedSearcher:
             # the local legs of a whole exchange group go to the engine together at flush(): one scan launch per
             # group (the caller keeps the query tensors alive until then -- they are rows of its own buffers)
             self._pending.append((d_query, d_terms, int(n_terms), self.send[slot][g]))
-        else:
+        elif not self._filtered:
             self.engine.legs(d_query, d_terms, n_terms, self.k, self.send[slot][g])
+        else:
+            self.engine.legs(d_query, d_terms, n_terms, self.k, self.send[slot][g], *self._allow)
         self._filled += 1
         if self._filled == self.group:
             self.flush()
@@ -136,7 +165,10 @@ class ShardedSearcher:
         slot, eng, k = self._slot, self.engine, self.k
         if self._pending:
             qs, ts, nts, outs = zip(*self._pending)
-            eng.legs_group(qs, ts, nts, k, outs)
+            if not self._filtered:
+                eng.legs_group(qs, ts, nts, k, outs)
+            else:
+                eng.legs_group(qs, ts, nts, k, outs, *self._allow)
             self._pending = []
         ctx = torch.cuda.stream(eng.comm_stream) if self.cuda else _NullCtx()
         with ctx:

@@ -38,8 +38,10 @@ def test_sharded_pipeline_world1_rccl():
         bi = Bm25Index(corpus, k1=1.7, b=0.83, epsilon=0.05)
         ref = BM25Okapi(corpus, k1=1.7, b=0.83, epsilon=0.05)
         idx = Index(0)
-        idx.dense_load(e, doc_id_base=1000)
-        idx.bm25_load(bi.indptr, bi.post_doc, bi.post_tf, bi.idf, bi.doc_len, bi.avgdl, bi.k1, bi.b, doc_id_base=1000)
+        sid = (np.arange(n) * 7 % 5).astype(np.uint16)  # 5 interned sources
+        idx.dense_load(e, source_id=sid, doc_id_base=1000)
+        idx.bm25_load(bi.indptr, bi.post_doc, bi.post_tf, bi.idf, bi.doc_len, bi.avgdl, bi.k1, bi.b, source_id=sid,
+                      doc_id_base=1000)
         engine = HipShardEngine(idx, device)
         rng = np.random.default_rng(3)
         queries, toks_all = [], []
@@ -56,22 +58,28 @@ def test_sharded_pipeline_world1_rccl():
             nt.append(len(t))
         # group=3: the local legs of an exchange group go to the library in one call (grouped scan launches, a
         # partial group at drain); group=1: one call per query
-        for rounds, group in ((0, 3), (1, 3), (2, 1), (3, 4)):  # 16 submissions through 4 slots, drained once per round
-            if rounds in (0, 2, 3):
+        allow = np.array([1, 0, 1, 1, 0], dtype=np.uint8)
+        # rounds 4 and 5: the same with a source filter on both legs (grouped call, then one call per query)
+        for rounds, group in ((0, 3), (1, 3), (2, 1), (3, 4), (4, 3), (5, 1)):  # drained once per round
+            if rounds in (0, 2, 3, 4, 5):
                 searcher = ShardedSearcher(engine, k=k, top_n=top_n, w_dense=5.0, w_bm25=1.0, wrrf_k=40, depth=4,
                                            group=group, device=device)
+            mask = None
+            if rounds >= 4:
+                searcher.set_filter(allow, allow)
+                mask = allow.astype(bool)[sid]
             slots = [searcher.submit(Q[i], T[i], nt[i]) for i in range(4)]
             searcher.drain()
             for i, slot in enumerate(slots):
                 ids, scores = searcher.result(slot)
                 sims = ref_search.dense_scores(queries[i], e)
-                dl = (ref_search.canonical_topk(sims, k) + 1000).tolist()
-                bl = (ref_search.canonical_topk(ref.get_scores(toks_all[i]), k) + 1000).tolist()
+                dl = (ref_search.canonical_topk(sims, k, mask) + 1000).tolist()
+                bl = (ref_search.canonical_topk(ref.get_scores(toks_all[i]), k, mask) + 1000).tolist()
                 want = ref_search.weighted_reciprocal_rank_fusion([(dl, "d"), (bl, "b")], {"d": 5.0, "b": 1.0}, 40)[:top_n]
                 assert ids.tolist() == [j for j, _ in want], (rounds, i)
                 assert scores.tolist() == [s for _, s in want]
-        # the single-call fused path gives the same answer
-        fid, fs = idx.hybrid_search(queries[0], bi.term_ids(toks_all[0]), k, 5.0, 1.0, 40, top_n)
+        # the single-call fused path gives the same answer (the last round ran filtered)
+        fid, fs = idx.hybrid_search(queries[0], bi.term_ids(toks_all[0]), k, 5.0, 1.0, 40, top_n, allow, allow)
         ids, scores = searcher.result(slots[0])
         assert fid.tolist() == ids.tolist() and fs.tolist() == scores.tolist()
     finally:

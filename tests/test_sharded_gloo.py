@@ -27,8 +27,9 @@ def _free_port():
 class OracleShardEngine:
     """Duck-types anrag.sharded.HipShardEngine on CPU tensors."""
 
-    def __init__(self, e_local, lo, glob: CsrBM25, corpus_local):
+    def __init__(self, e_local, lo, glob: CsrBM25, corpus_local, sid_local=None):
         self.e, self.lo = e_local, lo
+        self.sid = sid_local  # interned source id per local row (the same numbering on every rank)
         self.glob = glob
         # shard-local postings over the GLOBAL vocabulary, global idf / avgdl
         n_terms = len(glob.vocab)
@@ -57,15 +58,18 @@ class OracleShardEngine:
         rec[: len(docs), 1] = docs
         out.copy_(torch.from_numpy(rec))
 
-    def legs(self, d_query, d_terms, n_terms, k, out):
+    def prepare_allow(self, allow_source):
+        return None if allow_source is None else np.asarray(allow_source, dtype=bool)
+
+    def legs(self, d_query, d_terms, n_terms, k, out, allow_dense=None, allow_bm25=None):
         q = d_query.numpy()
         sims = ref_search.dense_scores(q, self.e)
-        top = ref_search.canonical_topk(sims, k)
+        top = ref_search.canonical_topk(sims, k, None if allow_dense is None else allow_dense[self.sid])
         self._write(out[:k], top + self.lo, sims[top].astype(np.float64), k)
         terms = d_terms.numpy()[:n_terms].tolist()
         sc = csr_get_scores(self.indptr, self.post_doc, self.post_tf, self.glob.idf, self.doc_len, self.glob.avgdl,
                             self.glob.k1, self.glob.b, terms)
-        top = ref_search.canonical_topk(sc, k)
+        top = ref_search.canonical_topk(sc, k, None if allow_bm25 is None else allow_bm25[self.sid])
         self._write(out[k:], top + self.lo, sc[top], k)
 
     def merge_fuse(self, lists, n_lists, k, stride, w_dense, w_bm25, wrrf_k, top_n, n_queries, out, count):
@@ -90,9 +94,9 @@ class OracleShardEngine:
 class GroupedOracleShardEngine(OracleShardEngine):
     """The same with the product engine's group call, so that the searcher takes its deferred-legs route."""
 
-    def legs_group(self, queries, terms, n_terms, k, outs):
+    def legs_group(self, queries, terms, n_terms, k, outs, allow_dense=None, allow_bm25=None):
         for q, t, nt, out in zip(queries, terms, n_terms, outs):
-            self.legs(q, t, nt, k, out)
+            self.legs(q, t, nt, k, out, allow_dense, allow_bm25)
 
 
 def _worker(rank, world, port, ret, grouped=False):
@@ -107,11 +111,17 @@ def _worker(rank, world, port, ret, grouped=False):
     e = synth_dense(n, d, 6)
     glob = CsrBM25(corpus, k1=1.7, b=0.83, epsilon=0.05)
     lo, hi = shard_bounds(n, world, rank)
-    eng = (GroupedOracleShardEngine if grouped else OracleShardEngine)(e[lo:hi], lo, glob, corpus[lo:hi])
+    sid = (np.arange(n) * 7 % 5).astype(np.int64)  # 5 "sources", the same numbering on every rank
+    eng = (GroupedOracleShardEngine if grouped else OracleShardEngine)(e[lo:hi], lo, glob, corpus[lo:hi], sid[lo:hi])
     rng = np.random.default_rng(11)
     ok = True
-    for group in (1, 3):  # one query per all-gather, and grouped exchanges with a partial last group
+    # one query per all-gather, grouped exchanges with a partial last group, and a source filter on both legs
+    for group, allow in ((1, None), (3, None), (3, np.array([1, 0, 1, 1, 0], dtype=np.uint8))):
         searcher = ShardedSearcher(eng, k=k, top_n=top_n, w_dense=5.0, w_bm25=1.0, wrrf_k=40, depth=2, group=group)
+        mask = None
+        if allow is not None:
+            searcher.set_filter(allow, allow)
+            mask = allow.astype(bool)[sid]
         tickets, wants = [], []
         for trial in range(5):
             target = int(rng.integers(n))
@@ -120,8 +130,8 @@ def _worker(rank, world, port, ret, grouped=False):
             terms = np.array(glob.term_ids(toks), dtype=np.int32)
             tickets.append(searcher.submit(torch.from_numpy(q), torch.from_numpy(terms), len(terms)))
             sims = ref_search.dense_scores(q, e)  # single-index oracle
-            dl = ref_search.canonical_topk(sims, k).tolist()
-            bl = ref_search.canonical_topk(glob.get_scores(toks), k).tolist()
+            dl = ref_search.canonical_topk(sims, k, mask).tolist()
+            bl = ref_search.canonical_topk(glob.get_scores(toks), k, mask).tolist()
             wants.append(ref_search.weighted_reciprocal_rank_fusion([(dl, "d"), (bl, "b")], {"d": 5.0, "b": 1.0},
                                                                     40)[:top_n])
             if group == 1 or trial == 4 or len(tickets) % (2 * group) == 0:
