@@ -52,7 +52,7 @@ def parse_args():
     ap.add_argument("--exchange-group", type=int, default=8,
                     help="N > 1: in-flight queries that share one all-gather (each is still scanned alone)")
     ap.add_argument("--filter", action="store_true",
-                    help="single-GPU diagnostic: source-prefix filter as retrieval_eval.py:280 passes it ('CG,NG'); rows "
+                    help="diagnostic: source-prefix filter as retrieval_eval.py:280 passes it ('CG,NG'); rows "
                          "carry one of 300 source ids, 15 %% of them outside the filter (SURVEY.md 8d)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-queries", type=int, default=12, help="queries of the bounded CPU sample")
@@ -105,8 +105,8 @@ def main():
     torch.cuda.synchronize()  # device-pointer operands must be complete: the library copies on its own stream
     src = allowed_rows = d_allow = None
     if args.filter:
-        if sharded or batched:
-            raise SystemExit("--filter is a single-GPU batch=1 diagnostic")
+        if batched:
+            raise SystemExit("--filter is a batch=1 diagnostic")
         src = ((np.arange(n_local, dtype=np.int64) + lo) % 300).astype(np.uint16)  # 300 guideline codes, cyclic
         allow = np.zeros(65536, np.uint8)
         allow[45:300] = 1  # ids 0..44 = the ~15 % QS/TA/PH sources the 'CG,NG' filter drops
@@ -182,6 +182,8 @@ def main():
         engine = HipShardEngine(idx, device)
         searcher = ShardedSearcher(engine, k=K, top_n=TOPN, w_dense=W_DENSE, w_bm25=W_BM25, wrrf_k=WRRF_K,
                                    depth=4, group=args.exchange_group, device=device)
+        if args.filter:
+            searcher.set_filter(allow[:300], allow[:300])  # source ids are global: (row % 300) on every rank
 
         def step(i):
             qi = i % args.queries
