@@ -45,8 +45,10 @@ def assert_ranking_matches(ref_rows, ref_scores, got_rows, got_scores, tol=0.0, 
                 assert last, f"{what}: rows differ in ranks [{start},{i}): {sorted(a)} vs {sorted(b)}"
                 if full_scores is not None:
                     fs = np.asarray(full_scores, dtype=np.float64)
+                    # a row the reference left out must tie with the reference's LAST entry (the cut), not with the
+                    # start of the run: a run can be a long chain of scores each within 2*tol of its neighbour
                     for r in b - a:
-                        assert abs(fs[r] - rs[start]) <= 2 * tol + 1e-30, (
-                            f"{what}: row {r} (score {fs[r]}) is not in the boundary tie group at {rs[start]}")
+                        assert abs(fs[r] - rs[i - 1]) <= 2 * tol + 1e-30, (
+                            f"{what}: row {r} (score {fs[r]}) does not tie with the cut at {rs[i - 1]}")
             start = i
     assert len(set(got_rows)) == len(got_rows), f"{what}: duplicate rows returned"
