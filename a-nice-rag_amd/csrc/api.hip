@@ -525,13 +525,14 @@ static int stage_terms(anrag_index *idx, hipStream_t st, const int32_t *term_ids
 int anrag_bm25_search_device(anrag_index *idx, const int32_t *d_term_ids, int32_t n_terms, int32_t k,
                              const uint32_t *d_allow_bits, anrag_candidate *d_out) {
     ANRAG_ENTER(idx);
-    if (int rc0 = settle_pipeline(idx)) return rc0;
-    if (int rc0 = settle_pipeline(idx)) return rc0;
     ANRAG_REQUIRE(idx->d_post_doc != nullptr, "BM25 search before anrag_bm25_load");
     ANRAG_REQUIRE(d_out && (n_terms == 0 || d_term_ids), "NULL operand");
     ANRAG_REQUIRE(n_terms >= 0, "n_terms must be >= 0");
     ANRAG_REQUIRE(k > 0 && k <= ANRAG_FUSED_K_MAX, "device path serves 1 <= k <= %d (got %d)", ANRAG_FUSED_K_MAX, k);
-    return launch_bm25(idx, idx->primary, d_term_ids, n_terms, k, d_allow_bits, d_out, nullptr);
+    // the BM25-only member of the query pipeline: it takes a slot like every other query (K3 on the secondary
+    // stream, the list merge on the fusion stream), so that its list set is never shared with a query in flight
+    const GroupQuery q{nullptr, d_term_ids, n_terms, d_out, nullptr};
+    return hybrid_enqueue_group(idx, kTailCandidates, &q, 1, k, 0.0, 1.0, 0.0, 0, nullptr, d_allow_bits);
 }
 
 int anrag_bm25_search(anrag_index *idx, const int32_t *term_ids, int32_t n_terms, int32_t k,
@@ -669,10 +670,15 @@ static int hybrid_enqueue_group(anrag_index *idx, TailMode tail, const GroupQuer
                                 double w_dense, double w_bm25, double wrrf_k, int32_t top_n,
                                 const uint32_t *d_allow_dense, const uint32_t *d_allow_bm25) {
     ANRAG_REQUIRE(n >= 1 && n <= kScanGroupMax && n <= kPipeSlots, "group of %d queries", n);
-    const bool use_dense = idx->d_emb != nullptr && (tail == kTailCandidates || w_dense > 0.0);
+    // legs: a query vector asks for the dense leg (one scan launch serves the whole group: all or none); term ids
+    // ask for the BM25 leg.  No term ids: BM25 is skipped as the reference skips it (search_engine.py:216-217) --
+    // except for a BM25-only candidate query, which then ranks all-zero scores like anrag_bm25_search does.
+    const bool use_dense = idx->d_emb != nullptr && q[0].d_query != nullptr && (tail != kTailFuse || w_dense > 0.0);
     bool use_bm25[kScanGroupMax];
     for (int i = 0; i < n; ++i) {
-        use_bm25[i] = idx->d_post_doc != nullptr && q[i].n_terms > 0 && (tail == kTailCandidates || w_bm25 > 0.0);
+        ANRAG_REQUIRE(!use_dense || q[i].d_query != nullptr, "query %d of the group has no query vector", i);
+        use_bm25[i] = idx->d_post_doc != nullptr && (tail != kTailFuse || w_bm25 > 0.0) &&
+                      (q[i].n_terms > 0 || (!use_dense && tail != kTailFuse));
         ANRAG_REQUIRE(use_dense || use_bm25[i], "hybrid search with neither a dense nor a BM25 leg");
     }
     hipStream_t P = idx->primary, S = idx->secondary, F = idx->fusion;
@@ -729,9 +735,9 @@ int anrag_hybrid_candidates_device(anrag_index *idx, const float *d_query, const
     ANRAG_ENTER(idx);
     ANRAG_REQUIRE(d_query && d_out, "NULL operand");
     ANRAG_REQUIRE(idx->d_emb != nullptr && idx->d_post_doc != nullptr, "needs both a dense and a BM25 shard");
-    ANRAG_REQUIRE(n_terms > 0 && d_term_ids, "needs at least one term id (use the dense path otherwise)");
+    ANRAG_REQUIRE(n_terms >= 0 && (n_terms == 0 || d_term_ids), "n_terms %d with NULL term ids", n_terms);
     ANRAG_REQUIRE(k > 0 && k <= ANRAG_FUSED_K_MAX, "1 <= k <= %d", ANRAG_FUSED_K_MAX);
-    return hybrid_enqueue(idx, kTailCandidates, d_query, d_term_ids, n_terms, k, 1.0, 1.0, 0.0, 0, d_allow_dense_bits,
+    return hybrid_enqueue(idx, kTailCandidates2k, d_query, d_term_ids, n_terms, k, 1.0, 1.0, 0.0, 0, d_allow_dense_bits,
                           d_allow_bm25_bits, d_out, nullptr);
 }
 
@@ -745,14 +751,14 @@ int anrag_hybrid_candidates_group_device(anrag_index *idx, const float *const *d
     ANRAG_REQUIRE(idx->d_emb != nullptr && idx->d_post_doc != nullptr, "needs both a dense and a BM25 shard");
     ANRAG_REQUIRE(k > 0 && k <= ANRAG_FUSED_K_MAX, "1 <= k <= %d", ANRAG_FUSED_K_MAX);
     for (int32_t i = 0; i < n_queries; ++i)
-        ANRAG_REQUIRE(d_queries[i] && d_out[i] && n_terms[i] > 0 && d_term_ids[i],
-                      "query %d: needs a query vector, at least one term id and an output block", i);
+        ANRAG_REQUIRE(d_queries[i] && d_out[i] && n_terms[i] >= 0 && (n_terms[i] == 0 || d_term_ids[i]),
+                      "query %d: needs a query vector, an output block and term ids for its n_terms", i);
     for (int32_t q0 = 0; q0 < n_queries; q0 += kScanGroup) {
         const int n = n_queries - q0 < kScanGroup ? n_queries - q0 : kScanGroup;
         GroupQuery g[kScanGroup];
         for (int i = 0; i < n; ++i)
             g[i] = GroupQuery{d_queries[q0 + i], d_term_ids[q0 + i], n_terms[q0 + i], d_out[q0 + i], nullptr};
-        int rc = hybrid_enqueue_group(idx, kTailCandidates, g, n, k, 1.0, 1.0, 0.0, 0, d_allow_dense_bits,
+        int rc = hybrid_enqueue_group(idx, kTailCandidates2k, g, n, k, 1.0, 1.0, 0.0, 0, d_allow_dense_bits,
                                       d_allow_bm25_bits);
         if (rc) return rc;
     }

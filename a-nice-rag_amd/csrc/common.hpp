@@ -194,7 +194,9 @@ int launch_bm25_lists(anrag_index *idx, hipStream_t st, const int32_t *d_terms, 
 // Tail of a query, ONE launch (tail.hip): merge the dense block lists of set `set` and/or the BM25 partition
 // lists into per-modality top-k, then either write both lists (kTailCandidates: d_out[0..k) dense,
 // [k..2k) BM25; with one modality only its k records at d_out[0..k)) or fuse them (kTailFuse: WRRF + top_n).
-enum TailMode { kTailFuse = 0, kTailCandidates = 1 };
+// kTailCandidates2k: always the two-list layout ([0,k) dense, [k,2k) BM25), an absent leg all padding (doc -1,
+// score -inf) -- the shape of one rank's all-gather payload, whatever the query skipped.
+enum TailMode { kTailFuse = 0, kTailCandidates = 1, kTailCandidates2k = 2 };
 int launch_tail(anrag_index *idx, hipStream_t st, int set, bool use_dense, bool use_bm25, int32_t k, TailMode mode,
                 double w_dense, double w_bm25, double wrrf_k, int32_t top_n, anrag_candidate *d_out,
                 int32_t *d_count);

@@ -90,10 +90,11 @@ __global__ __launch_bounds__(kTailThreads) void query_tail_kernel(TailArgs a) {
         }
     }
     __syncthreads();
-    if (a.mode == kTailCandidates) {
-        // one modality only: its k records at out[0..k); both: dense then BM25
-        const int first = a.n_dense > 0 ? 0 : k;
-        const int n_out = (a.n_dense > 0 && a.n_bm25 > 0) ? 2 * k : k;
+    if (a.mode != kTailFuse) {
+        // one modality only: its k records at out[0..k); both (or kTailCandidates2k): dense then BM25
+        const bool both = a.mode == kTailCandidates2k || (a.n_dense > 0 && a.n_bm25 > 0);
+        const int first = (both || a.n_dense > 0) ? 0 : k;
+        const int n_out = both ? 2 * k : k;
         if (tid < n_out) {
             anrag_candidate c;
             c.score = s_score[first + tid];

@@ -85,7 +85,9 @@ class HipShardEngine:
     def legs_group(self, queries, terms, n_terms, k: int, outs, allow_dense: Optional[torch.Tensor] = None,
                    allow_bm25: Optional[torch.Tensor] = None) -> None:
         """`legs` for the queries of one exchange group in ONE library call: the shard is scanned once per query,
-        but in a single launch per group of 4 (`anrag_hybrid_candidates_group_device`)."""
+        but in a single launch per group of up to 8 (`anrag_hybrid_candidates_group_device`).  A query with
+        n_terms == 0 skips BM25 (its BM25 half of the payload is padding), as the reference does for a query
+        without tokens (search_engine.py:216-217)."""
         import ctypes as C
 
         n = len(queries)
@@ -163,23 +165,25 @@ class ShardedSearcher:
         if n == 0:
             return
         slot, eng, k = self._slot, self.engine, self.k
-        if self._pending:
-            qs, ts, nts, outs = zip(*self._pending)
-            if not self._filtered:
-                eng.legs_group(qs, ts, nts, k, outs)
-            else:
-                eng.legs_group(qs, ts, nts, k, outs, *self._allow)
-            self._pending = []
-        ctx = torch.cuda.stream(eng.comm_stream) if self.cuda else _NullCtx()
-        with ctx:
-            if self.distributed:
-                dist.all_gather_into_tensor(self.recv[slot].view(-1), self.send[slot].view(-1), group=self.pg)
-            else:
-                self.recv[slot].view(-1).copy_(self.send[slot].view(-1))
-            eng.merge_fuse(self.recv[slot], self.world, k, self.group * 2 * k, self.w_dense, self.w_bm25, self.wrrf_k,
-                           self.top_n, n, self.out[slot], self.count[slot])
-        self._slot = (self._slot + 1) % self.depth
-        self._filled = 0
+        pending, self._pending = self._pending, []
+        try:
+            if pending:
+                qs, ts, nts, outs = zip(*pending)
+                if not self._filtered:
+                    eng.legs_group(qs, ts, nts, k, outs)
+                else:
+                    eng.legs_group(qs, ts, nts, k, outs, *self._allow)
+            ctx = torch.cuda.stream(eng.comm_stream) if self.cuda else _NullCtx()
+            with ctx:
+                if self.distributed:
+                    dist.all_gather_into_tensor(self.recv[slot].view(-1), self.send[slot].view(-1), group=self.pg)
+                else:
+                    self.recv[slot].view(-1).copy_(self.send[slot].view(-1))
+                eng.merge_fuse(self.recv[slot], self.world, k, self.group * 2 * k, self.w_dense, self.w_bm25,
+                               self.wrrf_k, self.top_n, n, self.out[slot], self.count[slot])
+        finally:  # a failed group is dropped, not retried: the searcher stays usable for the next submit
+            self._slot = (self._slot + 1) % self.depth
+            self._filled = 0
 
     def drain(self) -> None:
         """Flush a partial group and wait for everything submitted so far."""

@@ -186,6 +186,12 @@ int anrag_bm25_load(anrag_index *idx, const int64_t *indptr, int64_t n_terms,
 int anrag_bm25_search(anrag_index *idx, const int32_t *term_ids, int32_t n_terms, int32_t k,
                       const uint8_t *allow_source, int32_t n_sources, int64_t *out_doc,
                       double *out_score, int32_t *out_count);
+/* Same, operands in HBM, no host sync: the BM25-only member of the query pipeline (it
+ * takes a pipeline slot like anrag_hybrid_search_device does, so it may be mixed
+ * freely with hybrid and dense queries in flight).  K3 runs on the secondary
+ * stream, the list merge on the fusion stream: d_out (k records) is complete in
+ * fusion-stream order (anrag_index_sync waits for everything).  n_terms == 0
+ * ranks the all-zero score array, as anrag_bm25_search does. */
 int anrag_bm25_search_device(anrag_index *idx, const int32_t *d_term_ids, int32_t n_terms,
                              int32_t k, const uint32_t *d_allow_bits, anrag_candidate *d_out);
 /* BM25Okapi.get_scores(query) itself: out host, n_docs fp64. */
@@ -259,7 +265,9 @@ int anrag_merge_candidates_device(anrag_index *idx, const anrag_candidate *d_lis
  * candidates, d_out[k..2k) = BM25 candidates -- one rank's all-gather payload.
  * Dense runs on the primary stream, BM25 on the secondary; d_out is written
  * on the fusion stream, i.e. it is ready for whatever is enqueued on that
- * stream next (the all-gather). */
+ * stream next (the all-gather).  n_terms == 0: BM25 is skipped as the reference
+ * skips it for a query without tokens (search_engine.py:216-217) and the BM25 half
+ * of d_out is padding (doc -1, score -inf) -- the payload keeps its 2k shape. */
 int anrag_hybrid_candidates_device(anrag_index *idx, const float *d_query,
                                    const int32_t *d_term_ids, int32_t n_terms, int32_t k,
                                    const uint32_t *d_allow_dense_bits,

@@ -116,3 +116,70 @@ def test_concurrent_host_callers_match_serial():
         for workers in (2, 8, 16):
             with ThreadPoolExecutor(workers) as pool:
                 assert list(pool.map(ask, range(nq))) == serial, workers
+
+
+def test_bm25_device_then_hybrid_on_a_fresh_index():
+    """ADVICE r1 (api.hip:525): `anrag_bm25_search_device` used list set 0 on the primary stream without taking a
+    pipeline slot; the very next hybrid query of a fresh index (slot 0, secondary stream) could overwrite the set
+    under it.  It is a member of the pipeline now: both answers must equal the oracle's, call after call with no
+    host sync in between, BM25-only queries interleaved with hybrid ones and a query without terms."""
+    import torch
+    from oracle import ref_search
+    from oracle.make_golden import synth_chunks, synth_dense
+    from oracle.ref_bm25 import BM25Okapi
+    from anrag import _native as nat
+    from anrag.bm25_index import Bm25Index
+    from anrag.index import Index
+
+    dev = torch.device("cuda", 0)
+    n, d, k = 30000, 256, 25
+    chunks = [c for c in synth_chunks(n + 1500, 41) if c["tokens"]][:n]
+    corpus = [c["tokens"] for c in chunks]
+    e = synth_dense(n, d, 42)
+    bi = Bm25Index(corpus, 1.7, 0.83, 0.05)
+    ref = BM25Okapi(corpus, 1.7, 0.83, 0.05)
+    rng = np.random.default_rng(43)
+    nq = 40
+    rows = rng.integers(0, n, nq)
+    q = e[rows] + 0.05 * rng.standard_normal((nq, d), dtype=np.float32)
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    toks = [[str(t) for t in rng.choice(corpus[r], size=int(rng.integers(1, 9)))] for r in rows]
+    toks[5] = []  # BM25-only with no terms: the all-zero score array is ranked (rows 0..k-1), like anrag_bm25_search
+    terms = [bi.term_ids(t) for t in toks]
+    lib = nat.load_library()
+    Q = torch.from_numpy(q).to(dev)
+    T = torch.full((nq, 16), -1, dtype=torch.int32, device=dev)
+    for i, t in enumerate(terms):
+        T[i, : len(t)] = torch.from_numpy(t).to(dev)
+    for first in ("bm25", "hybrid"):
+        with Index(0) as idx:  # FRESH index each time: sequence number 0 is the slot the old code shared
+            idx.dense_load(e)
+            idx.bm25_load(bi.indptr, bi.post_doc, bi.post_tf, bi.idf, bi.doc_len, bi.avgdl, bi.k1, bi.b)
+            out_b = torch.zeros((nq, k, 2), dtype=torch.int64, device=dev)
+            out_f = torch.zeros((nq, 10, 2), dtype=torch.int64, device=dev)
+            cnt_f = torch.zeros(nq, dtype=torch.int32, device=dev)
+            torch.cuda.synchronize()
+            for i in range(nq):
+                bm_turn = (i % 2 == 0) == (first == "bm25")
+                if bm_turn or i == 5:
+                    nat.check(lib.anrag_bm25_search_device(idx.handle, T[i].data_ptr(), len(terms[i]), k, None,
+                                                           out_b[i].data_ptr()))
+                else:
+                    nat.check(lib.anrag_hybrid_search_device(idx.handle, Q[i].data_ptr(), T[i].data_ptr(), len(terms[i]),
+                                                             k, 5.0, 1.0, 40.0, 10, None, None, out_f[i].data_ptr(),
+                                                             cnt_f[i:].data_ptr()))
+            idx.sync()
+            ob, of, cf = out_b.cpu().numpy(), out_f.cpu().numpy(), cnt_f.cpu().numpy()
+            for i in range(nq):
+                scores = ref.get_scores(toks[i])
+                bl = ref_search.canonical_topk(scores, k)
+                bm_turn = (i % 2 == 0) == (first == "bm25")
+                if bm_turn or i == 5:
+                    assert ob[i, :, 1].tolist() == bl.tolist(), (first, i)
+                    assert np.array_equal(ob[i, :, 0].copy().view(np.float64), scores[bl]), (first, i)
+                else:
+                    dl = ref_search.canonical_topk(ref_search.dense_scores(q[i], e), k).tolist()
+                    want = ref_search.weighted_reciprocal_rank_fusion([(dl, "d"), (bl.tolist(), "b")],
+                                                                      {"d": 5.0, "b": 1.0}, 40)[:10]
+                    assert cf[i] == len(want) and of[i, :cf[i], 1].tolist() == [j for j, _ in want], (first, i)
+                    assert of[i, :cf[i], 0].copy().view(np.float64).tolist() == [s for _, s in want], (first, i)

@@ -66,6 +66,9 @@ class OracleShardEngine:
         sims = ref_search.dense_scores(q, self.e)
         top = ref_search.canonical_topk(sims, k, None if allow_dense is None else allow_dense[self.sid])
         self._write(out[:k], top + self.lo, sims[top].astype(np.float64), k)
+        if n_terms == 0:  # no tokens: the BM25 leg is skipped (search_engine.py:216-217), its half is padding
+            self._write(out[k:], [], [], k)
+            return
         terms = d_terms.numpy()[:n_terms].tolist()
         sc = csr_get_scores(self.indptr, self.post_doc, self.post_tf, self.glob.idf, self.doc_len, self.glob.avgdl,
                             self.glob.k1, self.glob.b, terms)
@@ -126,12 +129,14 @@ def _worker(rank, world, port, ret, grouped=False):
         for trial in range(5):
             target = int(rng.integers(n))
             q = synth_query(e, 100 + trial, target)
-            toks = [str(t) for t in rng.choice(corpus[target], size=4)]
+            # trial 2 asks without tokens (a query of stopwords only): dense-only, as the reference answers it
+            toks = [str(t) for t in rng.choice(corpus[target], size=4)] if trial != 2 else []
             terms = np.array(glob.term_ids(toks), dtype=np.int32)
-            tickets.append(searcher.submit(torch.from_numpy(q), torch.from_numpy(terms), len(terms)))
+            tickets.append(searcher.submit(torch.from_numpy(q), torch.from_numpy(np.resize(terms, max(len(terms), 1))),
+                                           len(terms)))
             sims = ref_search.dense_scores(q, e)  # single-index oracle
             dl = ref_search.canonical_topk(sims, k, mask).tolist()
-            bl = ref_search.canonical_topk(glob.get_scores(toks), k, mask).tolist()
+            bl = ref_search.canonical_topk(glob.get_scores(toks), k, mask).tolist() if toks else []
             wants.append(ref_search.weighted_reciprocal_rank_fusion([(dl, "d"), (bl, "b")], {"d": 5.0, "b": 1.0},
                                                                     40)[:top_n])
             if group == 1 or trial == 4 or len(tickets) % (2 * group) == 0:
