@@ -9,9 +9,7 @@
         the tokeniser's golden vectors and the id-space / stand-in corpus of the
         NICEQA Recall@10 measurement
   tests/golden/NICEQA.csv
-  a-nice-rag_amd/data/lemma_lexicon.json.gz
-        every (token_regular -> token_lemmatized) pair in those files where the two differ: the
-        WordNet-noun-lemmatiser stand-in of anrag.preprocess_bm25 (WordNet itself is not available offline)
+(the lemmatiser's observed-pair table is derived from these fixtures by tools/make_lemma_lexicon.py)
 """
 import ast
 import csv
@@ -26,7 +24,6 @@ GOLD = os.path.join(REPO, "tests", "golden")
 
 
 def main():
-    lex = {}
     for name in ("suggested_queries_bm25_preprocessed", "test_queries_bm25"):
         rows = []
         with open(os.path.join(REF, name + ".csv"), encoding="utf-8") as f:
@@ -34,18 +31,11 @@ def main():
                 reg = ast.literal_eval(r["tokens_regular"])
                 lem = ast.literal_eval(r["tokens_lemmatized"])
                 assert len(reg) == len(lem)
-                for a, b in zip(reg, lem):
-                    assert lex.setdefault(a, b) == b, (a, b, lex[a])
                 rows.append({"id": r["id"], "query": r["query"], "tokens_regular": reg, "tokens_lemmatized": lem})
         with gzip.open(os.path.join(GOLD, name + ".json.gz"), "wt", encoding="utf-8", compresslevel=9) as f:
             json.dump(rows, f, ensure_ascii=False, separators=(",", ":"))
         print(name, len(rows))
     shutil.copyfile(os.path.join(REF, "NICEQA.csv"), os.path.join(GOLD, "NICEQA.csv"))
-    lex = {a: b for a, b in sorted(lex.items()) if a != b}
-    out = os.path.join(REPO, "a-nice-rag_amd", "data", "lemma_lexicon.json.gz")
-    with gzip.open(out, "wt", encoding="utf-8", compresslevel=9) as f:
-        json.dump(lex, f, ensure_ascii=False, separators=(",", ":"))
-    print("lexicon", len(lex))
 
 
 if __name__ == "__main__":
