@@ -15,7 +15,8 @@ from typing import Optional
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libanrag.so")
+# ANRAG_LIB: another build of the same library (the `make dbg` diagnostic build); there is still no other backend
+LIB_PATH = os.environ.get("ANRAG_LIB") or os.path.join(_HERE, "libanrag.so")
 
 OK = 0
 FUSED_K_MAX = 64

@@ -72,6 +72,18 @@ __global__ void bm25_part_ptr_kernel(const int64_t *__restrict__ indptr, const i
     part_ptr[gid] = lo;
 }
 
+// ------------------------------------------------------------------ diagnostic build only (make dbg):
+// wall-clock stamps (100 MHz) at the kernel's phase boundaries, one row per workgroup, in a buffer nothing else reads
+#ifdef ANRAG_K3_STAMPS
+__device__ unsigned long long g_k3_stamps[4096 * 8];
+#define K3_STAMP(i)                                                                     \
+    do {                                                                                \
+        if (threadIdx.x == 0 && blockIdx.x < 4096) g_k3_stamps[blockIdx.x * 8 + (i)] = wall_clock64(); \
+    } while (0)
+#else
+#define K3_STAMP(i) do {} while (0)
+#endif
+
 // ------------------------------------------------------------------ query kernel
 // LDS plan of one workgroup (dynamic, ~100 KB: one workgroup per CU, which is what one partition per CU wants):
 //   slice[4096] fp64 scores | staged postings: st_val[kStageCap] fp64 + st_doc[kStageCap] u16 (the selection's
@@ -80,7 +92,12 @@ constexpr int kStageCap = 6144;                    // staged postings per gather
 constexpr int kStagePerThread = kStageCap / kBm25Threads;
 constexpr uint16_t kNoDoc = 0xFFFF;                // staged posting outside this partition (rare-term scan)
 constexpr int kBm25LdsBytes = kMaxPartDocs * 8 + kStageCap * 8 + kStageCap * 2 + kTermBatch * (8 + 8 + 4 + 4) + 2048 * 4;
+constexpr int kSurvCap = 1024;                     // survivors of the selection bound kept in LDS (12 KB)
 static_assert(kBm25Waves * kListLen * (8 + 4) <= kStageCap * 8, "merge lists must fit in the staging area");
+static_assert((kSurvCap + kSurvCap / 2 + kWave + kWave / 2 + 4 + kWave / 2) * 8 <= kStageCap * 8,
+              "survivor lists must fit too");
+static_assert(kMaxPartDocs == 64 * 64 && kBm25Threads == 1024 && kWave % kBm25Waves == 0,
+              "the selection deals 64 x 64 documents to 64 groups of 16 lanes");
 
 template <bool FILTER, bool SCORES>
 __global__ __launch_bounds__(kBm25Threads) void bm25_kernel(
@@ -102,6 +119,10 @@ __global__ __launch_bounds__(kBm25Threads) void bm25_kernel(
     uint32_t *lds_r = reinterpret_cast<uint32_t *>(st_val + kBm25Waves * kListLen);
 
     const int tid = threadIdx.x;
+    K3_STAMP(0);
+#ifdef ANRAG_K3_STAMPS
+    const unsigned long long k3_cycles0 = __builtin_amdgcn_s_memtime();
+#endif
     const int32_t part = blockIdx.x;
     const int64_t lo = (int64_t)part * part_docs;
     const int64_t hi = lo + part_docs < n_docs ? lo + part_docs : n_docs;
@@ -143,6 +164,7 @@ __global__ __launch_bounds__(kBm25Threads) void bm25_kernel(
             t_cnt[tid] = e - a;  // <= part_docs (one posting per document and term) or < kFrequentDf
         }
         __syncthreads();
+        K3_STAMP(1);
         int32_t j0 = 0;
         while (j0 < nb) {
             // the round's terms [j0, j1): greedy, at least one (a term alone always fits)
@@ -181,6 +203,7 @@ __global__ __launch_bounds__(kBm25Threads) void bm25_kernel(
                 }
             }
             __syncthreads();
+            K3_STAMP(2);
             // apply, in query order
             int32_t off = 0;
             for (int32_t j = j0; j < j1; ++j) {
@@ -197,6 +220,7 @@ __global__ __launch_bounds__(kBm25Threads) void bm25_kernel(
         }
     }
     if (n_terms == 0) __syncthreads();
+    K3_STAMP(3);
 
     if constexpr (SCORES) {
         for (int i = tid; i < len; i += kBm25Threads) {
@@ -205,50 +229,183 @@ __global__ __launch_bounds__(kBm25Threads) void bm25_kernel(
             scores_out[lo + i] = ok ? slice[i] : neg_inf<double>();
         }
     } else {
-        // Selection over the LDS slice.  The sorting networks are what this costs, so they run as rarely as
-        // possible: a thread holds part_docs / 1024 <= 4 documents, and its BEST one is offered first -- 64
-        // candidates, one sort -- which makes the wave's k-th best so far a bound most of the remaining documents
-        // fail, so the other three rounds are a ballot and a few wave-uniform insertions (offering 64 documents per
-        // round in index order took ~4 sorts per wave).  Then the usual tree merge of the 16 wave lists.
-        WaveTopK<double> top;
-        top.init(k);
+        // Selection over the LDS slice: the partition's k best under (score desc, row asc), zero-score documents
+        // included.  Sorting networks are what a selection costs (a 64-wide fp64 sort is ~400 dependent VALU
+        // instructions; 16 of them + a 4-level merge took 8 us), so nothing is sorted:
+        //   1. a bound: the documents are dealt to 64 groups (16 lanes each) so that group g holds rows
+        //      g, 64 + (g+4)%64, 128 + (g+8)%64, ... -- every group spans the whole partition and the groups' lowest
+        //      rows are rows 0..63, which keeps the bound tight when scores tie (all-zero partitions are the common
+        //      case); a lane finds the best of its 4 documents, four DPP steps the group's; every group best is
+        //      RANKED among the 64 by counting (each of the 16 waves compares against 4 of them): the one of rank
+        //      k-1, tau, is a document with at least k-1 documents ahead of it;
+        //   2. survivors = documents not behind tau (typically 30-45 of 4,096), compacted into LDS;
+        //   3. <= 64 survivors: ranked by counting again, each written to its place of the partition's list.  More
+        //      (heavy ties): wave 0 takes them 64 at a time through the insertion / merge network; more than kSurvCap:
+        //      the general path below (every wave selects, tree merge).
+        double *surv_s = st_val;
+        uint32_t *surv_r = reinterpret_cast<uint32_t *>(st_val + kSurvCap);
+        double *cand_s = st_val + kSurvCap + kSurvCap / 2;
+        uint32_t *cand_r = reinterpret_cast<uint32_t *>(cand_s + kWave);
+        double *tau_s = cand_s + kWave + kWave / 2;
+        uint32_t *tau_r = reinterpret_cast<uint32_t *>(tau_s + 1);
+        int32_t *surv_n = reinterpret_cast<int32_t *>(tau_s + 2);
+        int32_t *rank_cnt = reinterpret_cast<int32_t *>(tau_s + 3);  // [64] ranks, summed with LDS atomics
+        const int lane = tid & (kWave - 1), wave = tid / kWave;
+        const int g = 4 * wave + (lane >> 4), gl = lane & 15;
+        constexpr int kCmp = kWave / kBm25Waves;  // comparisons per wave and ranked entry
         double sc[kPostPerThread];
+        uint32_t rw[kPostPerThread];
         bool okk[kPostPerThread];
-        int bu = 0;
+        double bs = neg_inf<double>();
+        uint32_t br = kNoRow;
 #pragma unroll
         for (int u = 0; u < kPostPerThread; ++u) {
-            const int i = tid + u * kBm25Threads;
+            const int j = gl + 16 * u;
+            const int i = 64 * j + ((g + 4 * j) & 63);
             okk[u] = i < len;
             sc[u] = neg_inf<double>();
+            rw[u] = kNoRow;
             if (okk[u]) {
                 sc[u] = slice[i];
                 if constexpr (FILTER) okk[u] = source_ok(lds_allow, src[lo + i]);
             }
-            // rows ascend with u: a strict > keeps the lower row among equal scores
-            if (u > 0 && okk[u] && (!okk[bu] || sc[u] > sc[bu])) bu = u;
-        }
-        {
-            double bs = sc[0];
-            bool bo = okk[0];
-#pragma unroll
-            for (int u = 1; u < kPostPerThread; ++u)
-                if (bu == u) {
+            if (okk[u]) {
+                rw[u] = (uint32_t)(lo + i);
+                if (br == kNoRow || sc[u] > bs) {  // rows ascend with u: a strict > keeps the lower row among equals
                     bs = sc[u];
-                    bo = okk[u];
+                    br = rw[u];
                 }
-            const uint32_t br = (uint32_t)(lo + tid + bu * kBm25Threads);
-            top.offer_lanes(bo && top.admits(bs, br), bs, br);
+            }
         }
+        if (tid == 0) {
+            *surv_n = 0;
+            *tau_s = neg_inf<double>();
+            *tau_r = kNoRow;  // stays so when fewer than k groups hold a document: then everything survives
+        }
+        if (tid < kWave) rank_cnt[tid] = 0;
+        // best of the group: butterfly over its 16 lanes (every lane ends with it)
+        cmp_exchange<1>(bs, br, true);
+        cmp_exchange<2>(bs, br, true);
+        cmp_exchange<4>(bs, br, true);
+        cmp_exchange<8>(bs, br, true);
+        if (gl == 0) {
+            cand_s[g] = bs;
+            cand_r[g] = br;
+        }
+        __syncthreads();
+        {  // rank of group best `lane` among the 64: this wave's share of the comparisons
+            const double ms = cand_s[lane];
+            const uint32_t mr = cand_r[lane];
+            int c = 0;
 #pragma unroll
-        for (int u = 0; u < kPostPerThread; ++u) {
-            const uint32_t r = (uint32_t)(lo + tid + u * kBm25Threads);
-            top.offer_lanes(okk[u] && u != bu && top.admits(sc[u], r), sc[u], r);
+            for (int t = 0; t < kCmp; ++t) c += beats(cand_s[wave * kCmp + t], cand_r[wave * kCmp + t], ms, mr) ? 1 : 0;
+            if (c) atomicAdd(&rank_cnt[lane], c);
         }
-        block_merge(top, lds_s, lds_r, kBm25Waves);
-        if (threadIdx.x < kWave) {
-            blk_score[blockIdx.x * kListLen + threadIdx.x] = top.s;
-            blk_row[blockIdx.x * kListLen + threadIdx.x] = top.r;
+        __syncthreads();
+        if (wave == 0 && rank_cnt[lane] == k - 1 && cand_r[lane] != kNoRow) {  // rows are unique: at most one lane
+            *tau_s = cand_s[lane];
+            *tau_r = cand_r[lane];
         }
+        __syncthreads();
+        K3_STAMP(4);
+        if (tid < kWave) rank_cnt[tid] = 0;  // for the survivors' ranks (read again only behind the next barrier)
+        {
+            const double ts = *tau_s;
+            const uint32_t tr = *tau_r;
+            unsigned long long m[kPostPerThread];
+            int total = 0;
+#pragma unroll
+            for (int u = 0; u < kPostPerThread; ++u) {
+                m[u] = __ballot(okk[u] && !beats(ts, tr, sc[u], rw[u]));
+                total += __builtin_popcountll(m[u]);
+            }
+            int base = 0;
+            if (total > 0) {
+                if (lane == 0) base = atomicAdd(surv_n, total);
+                base = __builtin_amdgcn_readfirstlane(base);
+            }
+#pragma unroll
+            for (int u = 0; u < kPostPerThread; ++u) {
+                if ((m[u] >> lane) & 1ull) {
+                    const int pos = base + __builtin_popcountll(m[u] & ((1ull << lane) - 1ull));
+                    if (pos < kSurvCap) {
+                        surv_s[pos] = sc[u];
+                        surv_r[pos] = rw[u];
+                    }
+                }
+                base += __builtin_popcountll(m[u]);
+            }
+        }
+        __syncthreads();
+        K3_STAMP(5);
+        const int n_surv = *surv_n;
+        if (n_surv <= kWave) {
+            {
+                const bool in = lane < n_surv;
+                const double ms = in ? surv_s[lane] : neg_inf<double>();
+                const uint32_t mr = in ? surv_r[lane] : kNoRow;
+                int c = 0;
+#pragma unroll
+                for (int t = 0; t < kCmp; ++t) {
+                    const int o = wave * kCmp + t;
+                    c += (o < n_surv && beats(surv_s[o], surv_r[o], ms, mr)) ? 1 : 0;
+                }
+                if (c) atomicAdd(&rank_cnt[lane], c);
+            }
+            __syncthreads();
+            if (wave == 0) {
+                const bool in = lane < n_surv;
+                const int rank = in ? rank_cnt[lane] : lane;  // padding keeps its place behind the survivors
+                blk_score[blockIdx.x * kListLen + rank] = in ? surv_s[lane] : neg_inf<double>();
+                blk_row[blockIdx.x * kListLen + rank] = in ? surv_r[lane] : kNoRow;
+            }
+        } else {
+            WaveTopK<double> top;
+            top.init(k);
+            if (n_surv <= kSurvCap) {
+                if (wave == 0) {
+                    for (int c = 0; c < n_surv; c += kWave) {
+                        const bool in = c + lane < n_surv;
+                        const double cs = in ? surv_s[c + lane] : neg_inf<double>();
+                        const uint32_t cr = in ? surv_r[c + lane] : kNoRow;
+                        top.offer_lanes(in && top.admits(cs, cr), cs, cr);
+                    }
+                }
+            } else {
+                // general path: every wave selects from its own documents (a thread's best first, so that one sort
+                // sets a bound most of the rest fail), then the tree merge of the 16 wave lists
+                __syncthreads();  // the survivor area is about to be reused by the merge lists
+                int bu = 0;
+#pragma unroll
+                for (int u = 1; u < kPostPerThread; ++u)
+                    if (okk[u] && (!okk[bu] || beats(sc[u], rw[u], sc[bu], rw[bu]))) bu = u;
+                {
+                    double fs = sc[0];
+                    uint32_t fr = rw[0];
+                    bool fo = okk[0];
+#pragma unroll
+                    for (int u = 1; u < kPostPerThread; ++u)
+                        if (bu == u) {
+                            fs = sc[u];
+                            fr = rw[u];
+                            fo = okk[u];
+                        }
+                    top.offer_lanes(fo && top.admits(fs, fr), fs, fr);
+                }
+#pragma unroll
+                for (int u = 0; u < kPostPerThread; ++u)
+                    top.offer_lanes(okk[u] && u != bu && top.admits(sc[u], rw[u]), sc[u], rw[u]);
+                block_merge(top, lds_s, lds_r, kBm25Waves);
+            }
+            if (threadIdx.x < kWave) {
+                blk_score[blockIdx.x * kListLen + threadIdx.x] = top.s;
+                blk_row[blockIdx.x * kListLen + threadIdx.x] = top.r;
+            }
+        }
+        K3_STAMP(6);
+#ifdef ANRAG_K3_STAMPS
+        if (threadIdx.x == 0 && blockIdx.x < 4096) g_k3_stamps[blockIdx.x * 8 + 7] = __builtin_amdgcn_s_memtime() - k3_cycles0;
+#endif
     }
 }
 
@@ -447,3 +604,9 @@ int launch_bm25(anrag_index *idx, hipStream_t st, const int32_t *d_terms, int32_
 }
 
 }  // namespace anrag
+
+#ifdef ANRAG_K3_STAMPS
+extern "C" int anrag_debug_k3_stamps(unsigned long long *out, int n_words) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(anrag::g_k3_stamps), (size_t)n_words * 8);
+}
+#endif
