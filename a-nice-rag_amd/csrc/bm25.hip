@@ -24,6 +24,7 @@
 //   * selection runs on the LDS slice (wave_topk.hpp), zero-score documents included, as the
 //     reference ranks them (:236-243); one sorted list per partition -> tail kernel (tail.hip).
 #include <algorithm>
+#include <cstdlib>
 #include <vector>
 
 #include "common.hpp"
@@ -31,11 +32,15 @@
 
 namespace anrag {
 
-constexpr int kBm25Threads = 1024;  // 16 waves: with one partition per CU the postings of a term are one
-constexpr int kBm25Waves = kBm25Threads / kWave;  // round trip (<= kPostPerThread loads per thread, all in flight)
-constexpr int kMaxPartDocs = 4096;
-constexpr int kPostPerThread = kMaxPartDocs / kBm25Threads;  // a term has at most one posting per document
-constexpr int kFrequentDf = kBm25Threads;  // rarer terms: the whole list is one load per thread, range-checked
+// Workgroup size: 1,024 threads for partitions of up to 4,096 documents, 256 for partitions of up to 1,024 (the
+// shards of a multi-GPU run: 125k documents over 256 CUs = 512 per partition).  What the kernel costs is
+// instructions per wave x waves (it moves a few tens of KB per workgroup): a quarter of the waves for a quarter of
+// the documents.
+constexpr int kBm25Threads = 1024;
+constexpr int kBm25ThreadsSmall = 256;
+constexpr int kPostPerThread = 4;  // documents per thread in the selection
+constexpr int kMaxPartDocs = kPostPerThread * kBm25Threads;
+constexpr int kFrequentDf = 1024;  // rarer terms carry no partition table: the whole list is gathered, range-checked
 constexpr int kTermBatch = 128;
 
 // ------------------------------------------------------------------ load-time kernels
@@ -75,69 +80,92 @@ __global__ void bm25_part_ptr_kernel(const int64_t *__restrict__ indptr, const i
 // ------------------------------------------------------------------ diagnostic build only (make dbg):
 // wall-clock stamps (100 MHz) at the kernel's phase boundaries, one row per workgroup, in a buffer nothing else reads
 #ifdef ANRAG_K3_STAMPS
-__device__ unsigned long long g_k3_stamps[4096 * 8];
-#define K3_STAMP(i)                                                                     \
-    do {                                                                                \
-        if (threadIdx.x == 0 && blockIdx.x < 4096) g_k3_stamps[blockIdx.x * 8 + (i)] = wall_clock64(); \
+__device__ unsigned long long g_k3_stamps[4096 * 12];
+// stamps go to LDS (a global store in front of a barrier would make the barrier wait ~1 us for its acknowledgement and
+// bill it to the phase) and to the buffer at the very end
+#define K3_STAMP(i)                                                              \
+    do {                                                                         \
+        if (threadIdx.x == 0) k3_lds_stamps[(i)] = wall_clock64();               \
     } while (0)
 #else
 #define K3_STAMP(i) do {} while (0)
 #endif
 
 // ------------------------------------------------------------------ query kernel
-// LDS plan of one workgroup (dynamic, ~100 KB: one workgroup per CU, which is what one partition per CU wants):
-//   slice[4096] fp64 scores | staged postings: st_val[kStageCap] fp64 + st_doc[kStageCap] u16 (the selection's
-//   merge lists reuse the staging area afterwards) | term table | allow bitmap
-constexpr int kStageCap = 6144;                    // staged postings per gather round
-constexpr int kStagePerThread = kStageCap / kBm25Threads;
-constexpr uint16_t kNoDoc = 0xFFFF;                // staged posting outside this partition (rare-term scan)
-constexpr int kBm25LdsBytes = kMaxPartDocs * 8 + kStageCap * 8 + kStageCap * 2 + kTermBatch * (8 + 8 + 4 + 4) + 2048 * 4;
+// LDS plan of one workgroup (dynamic, ~60 KB):
+//   slice[4096] fp64 scores | work area (the selection's survivor / merge lists) | term table | allow bitmap |
+//   the gather round's slot table.  Postings are NOT staged in LDS: they go from HBM to registers and from there
+//   into the slice.
+constexpr int kWorkDoubles = 2048;                 // work area, 16 KB
+constexpr int kRoundTerms = 16;                    // query terms gathered per round at most
+constexpr int kRoundSlots = 16;                    // (term, 1024-posting chunk) pairs per round = loads per thread
+constexpr int bm25_lds_bytes(int threads) {
+    return kPostPerThread * threads * 8 + kWorkDoubles * 8 + kTermBatch * (8 + 8 + 4 + 4) + 2048 * 4 +
+           kRoundSlots * (8 + 8 + 4) + 16 + 12 * 8;
+}
 constexpr int kSurvCap = 1024;                     // survivors of the selection bound kept in LDS (12 KB)
-static_assert(kBm25Waves * kListLen * (8 + 4) <= kStageCap * 8, "merge lists must fit in the staging area");
-static_assert((kSurvCap + kSurvCap / 2 + kWave + kWave / 2 + 4 + kWave / 2) * 8 <= kStageCap * 8,
+static_assert(kBm25Threads / kWave * kListLen * (8 + 4) <= kWorkDoubles * 8, "merge lists must fit in the work area");
+static_assert((kSurvCap + kSurvCap / 2 + kWave + kWave / 2 + 4 + kWave / 2) * 8 <= kWorkDoubles * 8,
               "survivor lists must fit too");
-static_assert(kMaxPartDocs == 64 * 64 && kBm25Threads == 1024 && kWave % kBm25Waves == 0,
-              "the selection deals 64 x 64 documents to 64 groups of 16 lanes");
+static_assert(kMaxPartDocs == 64 * 64 && kBm25Threads % (64 * 4) == 0 && kBm25ThreadsSmall % (64 * 4) == 0,
+              "the selection deals the documents to 64 groups of THREADS / 64 lanes");
+static_assert((kFrequentDf + kBm25ThreadsSmall - 1) / kBm25ThreadsSmall <= kRoundSlots && kRoundTerms <= kWave,
+              "a term alone must fit a round");
 
-template <bool FILTER, bool SCORES>
-__global__ __launch_bounds__(kBm25Threads) void bm25_kernel(
+// Register budget of the 1,024-thread form: its 16 waves (4 per SIMD) must fit NEXT TO a scan workgroup (one wave of up
+// to 104 VGPRs per SIMD, dense_scan.hip), or K3 can only run between scans instead of under them: 5 waves per SIMD
+// asked for = at most 96 VGPRs each.
+template <bool FILTER, bool SCORES, int THREADS>
+__global__ __launch_bounds__(THREADS, THREADS == kBm25Threads ? 5 : 1) void bm25_kernel(
     const int64_t *__restrict__ indptr, const int32_t *__restrict__ post_doc, const double *__restrict__ impact,
     const double *__restrict__ idf, const int32_t *__restrict__ part_slot, const int32_t *__restrict__ part_ptr,
     int32_t n_parts, int32_t part_docs, int64_t n_docs, int64_t n_vocab, const int32_t *__restrict__ terms,
     int32_t n_terms, int32_t k, const uint16_t *__restrict__ src, const uint32_t *__restrict__ allow_bits,
-    double *__restrict__ blk_score, uint32_t *__restrict__ blk_row, double *__restrict__ scores_out) {
+    double *__restrict__ blk_score, uint32_t *__restrict__ blk_row, double *__restrict__ scores_out, int64_t sentinel) {
     extern __shared__ __attribute__((aligned(16))) unsigned char bm25_lds[];
     double *slice = reinterpret_cast<double *>(bm25_lds);
-    double *st_val = slice + kMaxPartDocs;
-    uint16_t *st_doc = reinterpret_cast<uint16_t *>(st_val + kStageCap);
-    double *t_w = reinterpret_cast<double *>(st_doc + kStageCap);
+    constexpr int WAVES = THREADS / kWave;
+    double *st_val = slice + kPostPerThread * THREADS;  // work area
+    double *t_w = st_val + kWorkDoubles;
     int64_t *t_base = reinterpret_cast<int64_t *>(t_w + kTermBatch);
     int32_t *t_begin = reinterpret_cast<int32_t *>(t_base + kTermBatch);
     int32_t *t_cnt = t_begin + kTermBatch;
     uint32_t *lds_allow = reinterpret_cast<uint32_t *>(t_cnt + kTermBatch);
+    int64_t *s_at = reinterpret_cast<int64_t *>(lds_allow + 2048);  // the gather round's slots (see there)
+    double *s_w = reinterpret_cast<double *>(s_at + kRoundSlots);
+    int32_t *s_cnt = reinterpret_cast<int32_t *>(s_w + kRoundSlots);
+    int32_t *r_info = s_cnt + kRoundSlots;
     double *lds_s = st_val;                                              // after the last term
-    uint32_t *lds_r = reinterpret_cast<uint32_t *>(st_val + kBm25Waves * kListLen);
+    uint32_t *lds_r = reinterpret_cast<uint32_t *>(st_val + WAVES * kListLen);
 
     const int tid = threadIdx.x;
-    K3_STAMP(0);
 #ifdef ANRAG_K3_STAMPS
+    unsigned long long *k3_lds_stamps = reinterpret_cast<unsigned long long *>(r_info + 4);
     const unsigned long long k3_cycles0 = __builtin_amdgcn_s_memtime();
 #endif
+    K3_STAMP(0);
+    int lane_zero;  // 0, opaque to the compiler: keeps table reads out of the scalarised (serialised) form
+    asm volatile("v_mov_b32 %0, 0" : "=v"(lane_zero));
     const int32_t part = blockIdx.x;
     const int64_t lo = (int64_t)part * part_docs;
     const int64_t hi = lo + part_docs < n_docs ? lo + part_docs : n_docs;
     const int32_t len = (int32_t)(hi - lo);
 
-    for (int i = tid; i < part_docs; i += kBm25Threads) slice[i] = 0.0;
+    for (int i = tid; i < part_docs; i += THREADS) slice[i] = 0.0;
     if constexpr (FILTER)
-        for (int i = tid; i < 2048; i += kBm25Threads) lds_allow[i] = allow_bits[i];
+        for (int i = tid; i < 2048; i += THREADS) lds_allow[i] = allow_bits[i];
 
-    // Term-at-a-time, but the HBM round trips are not: the postings of as many consecutive query terms as fit the
-    // staging area are GATHERED in one round (every load of the round is independent and in flight together),
-    // then APPLIED to the score slice term by term in query order, out of LDS, with a barrier between terms --
-    // two postings of one term never name the same document, postings of different terms stay ordered, so every
-    // fp64 sum is formed in exactly the reference's order.  (Walking the terms with one dependent HBM round trip
-    // each, the next one prefetched, took 34 us for 9 terms at 1M documents: 12 round trips, 6.7 % of HBM.)
+    // Term-at-a-time, but the HBM round trips are not: the postings of as many consecutive query terms as fit a ROUND
+    // are gathered together -- every load of the round independent and in flight at once -- into registers, then
+    // APPLIED to the score slice term by term in query order with a barrier between terms: two postings of one term
+    // never name the same document, postings of different terms stay ordered, so every fp64 sum is formed in exactly
+    // the reference's order.  A round is kRoundSlots slots; slot = 1,024 consecutive postings of one term's run in
+    // this partition, thread t <-> posting t of the slot, so nobody searches for "its" term: the slot table (16
+    // entries) is built by 16 lanes and read once by everybody.  Idle lanes and idle slots load the SENTINEL posting
+    // behind the last real one (document INT32_MAX: outside every partition), so the apply pass needs no counts.
+    // (History: one dependent HBM round trip per term took 34 us for 9 terms at 1M documents; packing the round's
+    // postings into an LDS staging area with a per-entry term search 24 us, 4.5 us of it the search's chain of
+    // dependent LDS reads -- LDS latency is ~300 cycles with 16 waves on the CU.)
     for (int32_t b0 = 0; b0 < n_terms; b0 += kTermBatch) {
         const int32_t nb = n_terms - b0 < kTermBatch ? n_terms - b0 : kTermBatch;
         __syncthreads();  // slice zeroed / previous batch's table no longer read
@@ -167,55 +195,87 @@ __global__ __launch_bounds__(kBm25Threads) void bm25_kernel(
         K3_STAMP(1);
         int32_t j0 = 0;
         while (j0 < nb) {
-            // the round's terms [j0, j1): greedy, at least one (a term alone always fits)
-            int32_t j1 = j0, total = 0;
-            while (j1 < nb && total + t_cnt[j1] <= kStageCap) total += t_cnt[j1++];
-            // gather: staged entry f <- posting (term, i); a thread's entries are f = tid + u * 1024.  Three
-            // separate passes -- addresses, loads, stores -- so that no use of a loaded value (and no branch) sits
-            // between two loads: all of a thread's loads are in flight together, one round trip per gather.
-            int64_t g_at[kStagePerThread];
-            {
-                int32_t j = j0, off = 0;  // term of the current entry and its first staged index
-#pragma unroll
-                for (int u = 0; u < kStagePerThread; ++u) {
-                    const int32_t f = tid + u * kBm25Threads;
-                    g_at[u] = 0;  // lanes past the end re-read posting 0 (one cache line, always there)
-                    if (f < total) {
-                        while (f >= off + t_cnt[j]) off += t_cnt[j++];
-                        g_at[u] = t_base[j] + t_begin[j] + (f - off);
+            // the round's terms [j0, j1): greedy, at least one (a term alone always fits), at most kRoundTerms.
+            // Lane t < kRoundTerms prices term j0 + t and writes its slots.
+            if (tid < kRoundTerms) {
+                // lane t's own count; the slots ahead of it by a scan over the 16 lanes (DPP row shifts, no LDS)
+                const int32_t mine = j0 + tid < nb ? t_cnt[j0 + tid] : 0;
+                const int32_t ns = (mine + THREADS - 1) / THREADS;
+                int32_t incl = ns;
+                incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xF, 0xF, true);  // row_shr:1, 0 shifted in
+                incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xF, 0xF, true);  // row_shr:2
+                incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xF, 0xF, true);  // row_shr:4
+                incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xF, 0xF, true);  // row_shr:8
+                const int32_t before = incl - ns;
+                const bool in = j0 + tid < nb && incl <= kRoundSlots;
+                s_at[tid] = sentinel;  // kRoundTerms == kRoundSlots lanes: every slot starts idle
+                s_w[tid] = 0.0;
+                s_cnt[tid] = 0;
+                if (tid == 0) r_info[1] = 0;
+                if (in && ns > 0) {  // same wave: these LDS writes follow the initialisation above in program order
+                    const int64_t at = t_base[j0 + tid] + t_begin[j0 + tid];
+                    const double w = t_w[j0 + tid];
+                    for (int v = 0; v < ns; ++v) {
+                        s_at[before + v] = at + (int64_t)v * THREADS;
+                        s_w[before + v] = w;
+                        s_cnt[before + v] = mine - v * THREADS < THREADS ? mine - v * THREADS : THREADS;
                     }
+                    atomicOr(reinterpret_cast<unsigned int *>(&r_info[1]), 1u << (before + ns - 1));  // the term's last slot
                 }
+                const unsigned long long fits = __ballot(in);  // a prefix of the lanes: slot sums only grow
+                if (tid == 0) r_info[0] = __builtin_popcountll(fits);  // terms in the round
             }
-            int32_t g_doc[kStagePerThread];
-            double g_val[kStagePerThread];
-#pragma unroll
-            for (int u = 0; u < kStagePerThread; ++u) {
-                g_doc[u] = post_doc[g_at[u]];
-                g_val[u] = impact[g_at[u]];
-            }
-#pragma unroll
-            for (int u = 0; u < kStagePerThread; ++u) {
-                const int32_t f = tid + u * kBm25Threads;
-                if (f < total) {
-                    const int64_t d = g_doc[u];
-                    st_doc[f] = (d >= lo && d < hi) ? (uint16_t)(d - lo) : kNoDoc;
-                    st_val[f] = g_val[u];
-                }
-            }
+            K3_STAMP(11);
             __syncthreads();
-            K3_STAMP(2);
-            // apply, in query order
-            int32_t off = 0;
-            for (int32_t j = j0; j < j1; ++j) {
-                const double w = t_w[j];
-                const int32_t cnt = t_cnt[j];
-                for (int32_t i = tid; i < cnt; i += kBm25Threads) {
-                    const uint16_t d = st_doc[off + i];
-                    if (d != kNoDoc) slice[d] = slice[d] + w * st_val[off + i];
+            K3_STAMP(10);
+            const int32_t j1 = j0 + r_info[0];
+            const uint32_t last_of_term = (uint32_t)r_info[1];
+            // gather: all of a thread's loads in flight together, one round trip.  The slot table is read through a
+            // lane offset the compiler cannot see through (it is 0): a provably uniform LDS read becomes
+            // ds_read + s_waitcnt + v_readfirstlane, i.e. one exposed LDS latency (~300 cycles here) PER ENTRY --
+            // 48 of them in a row cost 4 us; as ordinary per-lane reads they are issued together and waited for once.
+            int32_t g_doc[kRoundSlots];
+            double g_val[kRoundSlots];
+#pragma unroll
+            for (int h = 0; h < kRoundSlots; h += kRoundSlots / 2) {  // table entries half a round at a time: registers
+                int32_t c[kRoundSlots / 2];
+                int64_t a[kRoundSlots / 2];
+#pragma unroll
+                for (int u = 0; u < kRoundSlots / 2; ++u) {
+                    c[u] = s_cnt[h + u + lane_zero];
+                    a[u] = s_at[h + u + lane_zero];
                 }
-                off += cnt;
-                __syncthreads();  // term j is complete before term j+1 may touch the same document
+#pragma unroll
+                for (int u = 0; u < kRoundSlots / 2; ++u) {
+                    const int64_t at = tid < c[u] ? a[u] + tid : sentinel;
+                    g_doc[h + u] = post_doc[at];
+                    g_val[h + u] = impact[at];
+                }
             }
+            K3_STAMP(8);
+#ifdef ANRAG_K3_STAMPS
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+            K3_STAMP(9);
+            K3_STAMP(2);
+            // apply, in query order: a slot's postings name distinct documents; a barrier closes every term.  The
+            // terms' weights are read half a round at a time: with all 16 live next to the 48 registers of postings
+            // the kernel needed 116 VGPRs, and 16 waves of more than 104 cannot share a CU with a scan workgroup (96
+            // VGPRs on every SIMD) -- K3 then ran BETWEEN the scans instead of under them (125k-row shard: 61 -> 104
+            // us per query).
+#pragma unroll
+            for (int h = 0; h < kRoundSlots; h += kRoundSlots / 2) {
+                double g_w[kRoundSlots / 2];
+#pragma unroll
+                for (int u = 0; u < kRoundSlots / 2; ++u) g_w[u] = s_w[h + u + lane_zero];
+#pragma unroll
+                for (int u = 0; u < kRoundSlots / 2; ++u) {
+                    const int64_t d = g_doc[h + u];
+                    if (d >= lo && d < hi) slice[d - lo] = slice[d - lo] + g_w[u] * g_val[h + u];
+                    if ((last_of_term >> (h + u)) & 1u) __syncthreads();  // term complete before the next touches the same document
+                }
+            }
+            __syncthreads();  // the slot table is rewritten by the next round
             j0 = j1;
         }
     }
@@ -223,7 +283,7 @@ __global__ __launch_bounds__(kBm25Threads) void bm25_kernel(
     K3_STAMP(3);
 
     if constexpr (SCORES) {
-        for (int i = tid; i < len; i += kBm25Threads) {
+        for (int i = tid; i < len; i += THREADS) {
             bool ok = true;
             if constexpr (FILTER) ok = source_ok(lds_allow, src[lo + i]);
             scores_out[lo + i] = ok ? slice[i] : neg_inf<double>();
@@ -232,10 +292,10 @@ __global__ __launch_bounds__(kBm25Threads) void bm25_kernel(
         // Selection over the LDS slice: the partition's k best under (score desc, row asc), zero-score documents
         // included.  Sorting networks are what a selection costs (a 64-wide fp64 sort is ~400 dependent VALU
         // instructions; 16 of them + a 4-level merge took 8 us), so nothing is sorted:
-        //   1. a bound: the documents are dealt to 64 groups (16 lanes each) so that group g holds rows
-        //      g, 64 + (g+4)%64, 128 + (g+8)%64, ... -- every group spans the whole partition and the groups' lowest
+        //   1. a bound: the documents are dealt to 64 groups (THREADS / 64 lanes each) so that group g holds rows
+        //      g, 64 + (g+ROT)%64, 128 + (g+2 ROT)%64, ... -- every group spans the whole partition and the groups' lowest
         //      rows are rows 0..63, which keeps the bound tight when scores tie (all-zero partitions are the common
-        //      case); a lane finds the best of its 4 documents, four DPP steps the group's; every group best is
+        //      case); a lane finds the best of its 4 documents, DPP steps the group's; every group best is
         //      RANKED among the 64 by counting (each of the 16 waves compares against 4 of them): the one of rank
         //      k-1, tau, is a document with at least k-1 documents ahead of it;
         //   2. survivors = documents not behind tau (typically 30-45 of 4,096), compacted into LDS;
@@ -251,8 +311,10 @@ __global__ __launch_bounds__(kBm25Threads) void bm25_kernel(
         int32_t *surv_n = reinterpret_cast<int32_t *>(tau_s + 2);
         int32_t *rank_cnt = reinterpret_cast<int32_t *>(tau_s + 3);  // [64] ranks, summed with LDS atomics
         const int lane = tid & (kWave - 1), wave = tid / kWave;
-        const int g = 4 * wave + (lane >> 4), gl = lane & 15;
-        constexpr int kCmp = kWave / kBm25Waves;  // comparisons per wave and ranked entry
+        constexpr int LPG = THREADS / 64;  // lanes per group
+        constexpr int ROT = LPG == 16 ? 4 : 16;
+        const int g = tid / LPG, gl = tid % LPG;
+        constexpr int kCmp = kWave / WAVES;  // comparisons per wave and ranked entry
         double sc[kPostPerThread];
         uint32_t rw[kPostPerThread];
         bool okk[kPostPerThread];
@@ -260,8 +322,8 @@ __global__ __launch_bounds__(kBm25Threads) void bm25_kernel(
         uint32_t br = kNoRow;
 #pragma unroll
         for (int u = 0; u < kPostPerThread; ++u) {
-            const int j = gl + 16 * u;
-            const int i = 64 * j + ((g + 4 * j) & 63);
+            const int j = gl + LPG * u;
+            const int i = 64 * j + ((g + ROT * j) & 63);
             okk[u] = i < len;
             sc[u] = neg_inf<double>();
             rw[u] = kNoRow;
@@ -286,8 +348,10 @@ __global__ __launch_bounds__(kBm25Threads) void bm25_kernel(
         // best of the group: butterfly over its 16 lanes (every lane ends with it)
         cmp_exchange<1>(bs, br, true);
         cmp_exchange<2>(bs, br, true);
-        cmp_exchange<4>(bs, br, true);
-        cmp_exchange<8>(bs, br, true);
+        if constexpr (LPG == 16) {
+            cmp_exchange<4>(bs, br, true);
+            cmp_exchange<8>(bs, br, true);
+        }
         if (gl == 0) {
             cand_s[g] = bs;
             cand_r[g] = br;
@@ -375,27 +439,19 @@ __global__ __launch_bounds__(kBm25Threads) void bm25_kernel(
                 // general path: every wave selects from its own documents (a thread's best first, so that one sort
                 // sets a bound most of the rest fail), then the tree merge of the 16 wave lists
                 __syncthreads();  // the survivor area is about to be reused by the merge lists
-                int bu = 0;
-#pragma unroll
-                for (int u = 1; u < kPostPerThread; ++u)
-                    if (okk[u] && (!okk[bu] || beats(sc[u], rw[u], sc[bu], rw[bu]))) bu = u;
-                {
-                    double fs = sc[0];
-                    uint32_t fr = rw[0];
-                    bool fo = okk[0];
-#pragma unroll
-                    for (int u = 1; u < kPostPerThread; ++u)
-                        if (bu == u) {
-                            fs = sc[u];
-                            fr = rw[u];
-                            fo = okk[u];
-                        }
-                    top.offer_lanes(fo && top.admits(fs, fr), fs, fr);
-                }
+                double fs = neg_inf<double>();  // the thread's best document (rows ascend with u)
+                uint32_t fr = kNoRow;
 #pragma unroll
                 for (int u = 0; u < kPostPerThread; ++u)
-                    top.offer_lanes(okk[u] && u != bu && top.admits(sc[u], rw[u]), sc[u], rw[u]);
-                block_merge(top, lds_s, lds_r, kBm25Waves);
+                    if (okk[u] && (fr == kNoRow || sc[u] > fs)) {
+                        fs = sc[u];
+                        fr = rw[u];
+                    }
+                top.offer_lanes(fr != kNoRow && top.admits(fs, fr), fs, fr);
+#pragma unroll
+                for (int u = 0; u < kPostPerThread; ++u)
+                    top.offer_lanes(okk[u] && rw[u] != fr && top.admits(sc[u], rw[u]), sc[u], rw[u]);
+                block_merge(top, lds_s, lds_r, WAVES);
             }
             if (threadIdx.x < kWave) {
                 blk_score[blockIdx.x * kListLen + threadIdx.x] = top.s;
@@ -404,7 +460,10 @@ __global__ __launch_bounds__(kBm25Threads) void bm25_kernel(
         }
         K3_STAMP(6);
 #ifdef ANRAG_K3_STAMPS
-        if (threadIdx.x == 0 && blockIdx.x < 4096) g_k3_stamps[blockIdx.x * 8 + 7] = __builtin_amdgcn_s_memtime() - k3_cycles0;
+        if (threadIdx.x == 0 && blockIdx.x < 4096) {
+            k3_lds_stamps[7] = __builtin_amdgcn_s_memtime() - k3_cycles0;
+            for (int i = 0; i < 12; ++i) g_k3_stamps[blockIdx.x * 12 + i] = k3_lds_stamps[i];
+        }
 #endif
     }
 }
@@ -477,8 +536,15 @@ int bm25_load(anrag_index *idx, const int64_t *indptr, int64_t n_terms, const in
     idx->n_parts = (int32_t)((n_docs + pd - 1) / pd);
 
     if ((rc = bm25_alloc(idx, &idx->d_indptr, n_terms + 1))) return rc;
-    if ((rc = bm25_alloc(idx, &idx->d_post_doc, n_postings))) return rc;
-    if ((rc = bm25_alloc(idx, &idx->d_post_impact, n_postings))) return rc;
+    // + 1: the sentinel posting (document INT32_MAX, impact 0) idle lanes of the query kernel load
+    if ((rc = bm25_alloc(idx, &idx->d_post_doc, n_postings + 1))) return rc;
+    if ((rc = bm25_alloc(idx, &idx->d_post_impact, n_postings + 1))) return rc;
+    {
+        const int32_t no_doc = 0x7FFFFFFF;
+        const double zero = 0.0;
+        ANRAG_HIP(hipMemcpy(idx->d_post_doc + n_postings, &no_doc, sizeof(no_doc), hipMemcpyHostToDevice));
+        ANRAG_HIP(hipMemcpy(idx->d_post_impact + n_postings, &zero, sizeof(zero), hipMemcpyHostToDevice));
+    }
     if ((rc = bm25_alloc(idx, &idx->d_idf, n_terms))) return rc;
     if ((rc = bm25_alloc(idx, &idx->d_part_slot, n_terms))) return rc;
     ANRAG_HIP(hipMemcpy(idx->d_indptr, indptr, (size_t)(n_terms + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
@@ -565,14 +631,18 @@ int launch_bm25_lists(anrag_index *idx, hipStream_t st, const int32_t *d_terms, 
                       const uint32_t *d_allow_bits, double *d_scores_out, int set) {
     const uint32_t *allow = idx->d_bm25_src ? d_allow_bits : nullptr;
     static bool attr_set = false;
-    if (!attr_set) {  // ~100 KB of LDS per workgroup: above the 64 KB a kernel gets without asking
-#define ANRAG_BM25_ATTR(F, S)                                                                         \
-    ANRAG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&bm25_kernel<F, S>),                 \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, kBm25LdsBytes))
-        ANRAG_BM25_ATTR(false, false);
-        ANRAG_BM25_ATTR(false, true);
-        ANRAG_BM25_ATTR(true, false);
-        ANRAG_BM25_ATTR(true, true);
+    if (!attr_set) {  // dynamic LDS is asked for explicitly (up to 60 KB per workgroup)
+#define ANRAG_BM25_ATTR(F, S, T)                                                                      \
+    ANRAG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&bm25_kernel<F, S, T>),              \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, bm25_lds_bytes(T)))
+        ANRAG_BM25_ATTR(false, false, kBm25Threads);
+        ANRAG_BM25_ATTR(false, true, kBm25Threads);
+        ANRAG_BM25_ATTR(true, false, kBm25Threads);
+        ANRAG_BM25_ATTR(true, true, kBm25Threads);
+        ANRAG_BM25_ATTR(false, false, kBm25ThreadsSmall);
+        ANRAG_BM25_ATTR(false, true, kBm25ThreadsSmall);
+        ANRAG_BM25_ATTR(true, false, kBm25ThreadsSmall);
+        ANRAG_BM25_ATTR(true, true, kBm25ThreadsSmall);
 #undef ANRAG_BM25_ATTR
         attr_set = true;
     }
@@ -580,17 +650,25 @@ int launch_bm25_lists(anrag_index *idx, hipStream_t st, const int32_t *d_terms, 
     uint32_t *blk_r = idx->d_blk_row_b + (int64_t)set * idx->n_parts * kListLen;
     {
         LaunchTimer t(idx, ANRAG_KERNEL_BM25, st);
-#define ANRAG_BM25(F, S)                                                                                          \
-    bm25_kernel<F, S><<<idx->n_parts, kBm25Threads, kBm25LdsBytes, st>>>(                                          \
+    static const bool force_large = getenv("ANRAG_K3_LARGE") != nullptr;  // experiment knob: always 1,024 threads
+    const bool small = !force_large && idx->part_docs <= kPostPerThread * kBm25ThreadsSmall;
+#define ANRAG_BM25_T(F, S, T)                                                                                     \
+    bm25_kernel<F, S, T><<<idx->n_parts, T, bm25_lds_bytes(T), st>>>(                                              \
         idx->d_indptr, idx->d_post_doc, idx->d_post_impact, idx->d_idf, idx->d_part_slot, idx->d_part_ptr,        \
         idx->n_parts, idx->part_docs, idx->n_docs, idx->n_terms, d_terms, n_terms, k, idx->d_bm25_src, allow,     \
-        blk_s, blk_r, d_scores_out)
+        blk_s, blk_r, d_scores_out, idx->n_postings)
+#define ANRAG_BM25(F, S)                                                   \
+    do {                                                                   \
+        if (small) ANRAG_BM25_T(F, S, kBm25ThreadsSmall);                  \
+        else ANRAG_BM25_T(F, S, kBm25Threads);                             \
+    } while (0)
         if (d_scores_out) {
             if (allow) ANRAG_BM25(true, true); else ANRAG_BM25(false, true);
         } else {
             if (allow) ANRAG_BM25(true, false); else ANRAG_BM25(false, false);
         }
 #undef ANRAG_BM25
+#undef ANRAG_BM25_T
         ANRAG_HIP(hipGetLastError());
     }
     return ANRAG_OK;

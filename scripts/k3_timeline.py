@@ -34,19 +34,24 @@ for q in range(64):
     for rep in range(3):
         nat.check(lib.anrag_bm25_search_device(idx.handle, T[q].data_ptr(), nt[q], 25, None, out[q].data_ptr()))
         idx.sync()
-    buf = np.zeros(4096 * 8, dtype=np.uint64)
+    buf = np.zeros(4096 * 12, dtype=np.uint64)
     assert lib.anrag_debug_k3_stamps(buf.ctypes.data, buf.size) == 0
-    st = buf.reshape(4096, 8).astype(np.int64)
+    st = buf.reshape(4096, 12).astype(np.int64)
     live = st[:, 0] > 0
     st = st[live]
     t0 = st[:, 0].min()
     acc.append(np.concatenate([[np.median(st[:, 0] - t0), (st[:, 0] - t0).max()],
                                np.median(np.diff(st[:, :7], axis=1), axis=0),
                                [np.median(st[:, 6] - t0), (st[:, 6] - t0).max(), live.sum(),
+                                np.median(st[:, 8] - st[:, 1]), np.median(st[:, 9] - st[:, 8]), np.median(st[:, 2] - st[:, 9]),
+                                np.median(st[:, 10] - st[:, 1]), np.median(st[:, 11] - st[:, 1]),
                                 np.median(st[:, 7] / np.maximum(st[:, 6] - st[:, 0], 1))]]))
 a = np.mean(acc, axis=0) / 100.0  # 100 MHz -> us
 print(f"shader clock inside the kernel: {np.mean(acc, axis=0)[-1] * 100:.0f} MHz")
-print(f"n_docs={n}, workgroups {int(np.mean(acc, axis=0)[-2])}: start skew median {a[0]:.2f} max {a[1]:.2f} us")
+a = np.append(a, 0)
+print(f"slot table: 16 lanes {a[15]:.2f} us, then the barrier {a[14] - a[15]:.2f} us")
+print(f"gather = slot table {a[14]:.2f} + issue of the loads {a[11] - a[14]:.2f} + loads in flight {a[12]:.2f} us")
+print(f"n_docs={n}, workgroups {int(np.mean(acc, axis=0)[10])}: start skew median {a[0]:.2f} max {a[1]:.2f} us")
 for i, nm in enumerate(names):
     print(f"  {nm:32s} {a[2 + i]:6.2f} us (median over workgroups)")
 print(f"  end of workgroup: median {a[8]:.2f} us, last {a[9]:.2f} us after the first workgroup's start")

@@ -171,3 +171,33 @@ def test_dense_large_k():
             assert cnt[0] == len(want) and doc[0, :cnt[0]].tolist() == want.tolist()
             rows, sims = ref_search.similarity_search_with_embedding(q, e, None, k, None, canonical=True)
             assert_ranking_matches(rows, sims, doc[0, :cnt[0]], sc[0, :cnt[0]], 1e-4, None, f"dense large k={k}")
+
+
+def test_mid_size_partitions_vs_oracle():
+    """600k documents = partitions of 2,560 documents: the 1,024-thread form of K3 with partly filled lanes and a short
+    last partition, multi-term queries with a source filter, against the oracle's CSR scorer (bit-exact scores, exact
+    ranks).  (The fixtures above are <= 30k documents: partitions of 256, the 256-thread form.)"""
+    import torch
+    from oracle import ref_bm25, ref_search
+    from anrag import synth
+    from anrag.index import Index
+
+    dev = torch.device("cuda", 0)
+    n = 600_123
+    post = synth.bm25_postings(n, 50_000, 31, dev, median_len=30.0)
+    idf = synth.bm25_idf(post["df"].cpu().numpy(), n)
+    avgdl = post["total_len"] / n
+    sid = (np.arange(n) % 7).astype(np.uint16)
+    allow = np.array([1, 1, 0, 1, 0, 1, 1], dtype=np.uint8)
+    torch.cuda.synchronize()
+    post_doc, post_tf = post["post_doc"].cpu().numpy(), post["post_tf"].cpu().numpy()
+    with Index(0) as idx:
+        idx.bm25_load(post["indptr"], post_doc, post_tf, idf, post["doc_len"], avgdl, 1.7, 0.83, source_id=sid)
+        terms = [list(map(int, t)) for t in synth.bm25_queries(post, 5, 3)] + [[], [-1]]
+        for t in terms:
+            want = ref_bm25.csr_get_scores(post["indptr"], post_doc, post_tf, idf, post["doc_len"], avgdl, 1.7, 0.83, t)
+            assert np.array_equal(idx.bm25_scores(t), want), t
+            for k, flt in ((25, None), (64, allow), (3, allow)):
+                doc, sc, cnt = idx.bm25_search(t, k, flt)
+                order = ref_search.canonical_topk(want, k, None if flt is None else flt.astype(bool)[sid])
+                assert cnt == k and doc.tolist() == order.tolist() and np.array_equal(sc, want[order]), (t, k)

@@ -99,6 +99,31 @@ def test_bm25_properties_at_full_size(world):
         assert cnt == 25 and doc.tolist() == order.tolist() and np.array_equal(sc, s[order])
 
 
+def test_bm25_multi_term_queries_vs_oracle_at_full_size(world):
+    """9-term queries (bench.py's shape, one with a duplicated term, one with an unknown token) at 1M documents
+    against the oracle's CSR restatement of BM25Okapi.get_scores: every one of the 1M fp64 scores bit for bit, and
+    the fused top-25 == (score desc, row asc) over that array.  This is the 1,024-thread form of K3 (partitions of
+    4,096 documents); the small corpora of test_gpu_bm25.py run its 256-thread form."""
+    from oracle import ref_bm25, ref_search
+    from anrag import synth
+
+    idx, post, idf = world["idx"], world["post"], world["idf"]
+    post_doc, post_tf = post["post_doc"].cpu().numpy(), post["post_tf"].cpu().numpy()
+    terms = [list(map(int, t)) for t in synth.bm25_queries(post, 6, 17)]
+    terms[1][-1] = terms[1][0]       # a duplicated query token counts again
+    terms[2].insert(3, -1)           # a token outside the vocabulary contributes nothing
+    terms.append([int(np.argmax(np.diff(post["indptr"])))] * 2 + terms[0][:3])  # the most frequent term, twice
+    for t in terms:
+        want = ref_bm25.csr_get_scores(post["indptr"], post_doc, post_tf, idf, post["doc_len"], world["avgdl"],
+                                       1.7, 0.83, t)
+        got = idx.bm25_scores(t)
+        assert np.array_equal(got, want), t
+        for k in (1, 25, 64):
+            doc, sc, cnt = idx.bm25_search(t, k)
+            order = ref_search.canonical_topk(want, k)
+            assert cnt == k and doc.tolist() == order.tolist() and np.array_equal(sc, want[order]), (t, k)
+
+
 def test_hybrid_consistent_at_full_size(world):
     from oracle import ref_search
     from anrag import synth
