@@ -317,8 +317,8 @@ int anrag_dense_load(anrag_index *idx, const float *embeddings, int64_t n_rows, 
     }
     idx->dense_doc_base = doc_id_base;
     if (!idx->d_blk_score_f32) {
-        if ((rc = dev_alloc(idx, &idx->d_blk_score_f32, (int64_t)kPipeSlots * kMaxScanBlocks * kListLen))) return rc;
-        if ((rc = dev_alloc(idx, &idx->d_blk_row_a, (int64_t)kPipeSlots * kMaxScanBlocks * kListLen))) return rc;
+        if ((rc = dev_alloc(idx, &idx->d_blk_score_f32, (int64_t)kPipeSlots * kMaxScanLists * kListLen))) return rc;
+        if ((rc = dev_alloc(idx, &idx->d_blk_row_a, (int64_t)kPipeSlots * kMaxScanLists * kListLen))) return rc;
     }
     if ((rc = ensure_query_buffer(idx, (int64_t)64 * dim))) return rc;
     return ANRAG_OK;

@@ -22,7 +22,8 @@ constexpr int kScanGroupMax = 8;   // queries one scan launch can carry (dense_s
 constexpr int kPipeSlots = 32;     // queries in flight in the hybrid pipeline (list sets, events): four exchange
                                    // groups of 8, so a slow collective on the communication stream (which the tails
                                    // queue behind) does not stall the scans two groups later
-constexpr int kMaxScanBlocks = 256;  // one per CU; also bounds the final merge fan-in
+constexpr int kMaxScanBlocks = 256;  // one per CU
+constexpr int kMaxScanLists = kMaxScanBlocks * kScanWaves;  // K1 leaves one sorted list per WAVE (the tail merges them)
 constexpr uint32_t kNoRow = 0xFFFFFFFFu;
 
 void set_error(const char *fmt, ...);
@@ -109,7 +110,7 @@ struct anrag_index {
     double bm25_k1 = 0, bm25_b = 0, bm25_avgdl = 0;
 
     // ---- workspaces (sized at load; reused by every query on the stream that owns them)
-    float *d_blk_score_f32 = nullptr;  // [kPipeSlots][kMaxScanBlocks][kListLen]
+    float *d_blk_score_f32 = nullptr;  // [kPipeSlots][kMaxScanLists][kListLen]
     uint32_t *d_blk_row_a = nullptr;
     double *d_blk_score_f64 = nullptr;  // BM25 per-partition lists [kPipeSlots][n_parts][kListLen]
     uint32_t *d_blk_row_b = nullptr;
@@ -184,6 +185,7 @@ int drain_profile(anrag_index *idx);
 
 // ---- kernel launchers (each enqueues on `stream`, never syncs)
 int dense_scan_grid(const anrag_index *idx);
+inline int dense_scan_lists(const anrag_index *idx) { return dense_scan_grid(idx) * kScanWaves; }
 // K1 alone: one sorted list per workgroup into block-list set `set` (or every score into d_scores_out, k = 0)
 int launch_dense_scan(anrag_index *idx, hipStream_t stream, const float *d_query, int32_t k,
                       const uint32_t *d_allow_bits, float *d_scores_out, int set);

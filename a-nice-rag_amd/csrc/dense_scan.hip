@@ -14,7 +14,10 @@
 //     co-running kernels: profiles/r01_scan_config_sweep.txt);
 //   * the query slice of each lane lives in registers (CH float4), staged once per wave;
 //   * G-lane butterfly reduction, then the wave's register top-k (wave_topk.hpp);
-//   * per-workgroup LDS tree merge -> one sorted list per workgroup -> tail kernel (tail.hip).
+//   * one sorted list per WAVE -> tail kernel (tail.hip).  No workgroup merge here: a tree merge through LDS kept
+//     every CU away from HBM for 3-5 us per query (bitonic networks + barriers) -- 1 % of a 1M-row scan, 7 % of a
+//     125k-row one -- and the tail kernel merges off the scans' stream anyway; without it the waves of a workgroup
+//     never meet at a barrier and go on to the next query of a launch on their own.
 //   * the 6-step lane reduction is DPP row ops (no LDS traffic in the streaming loop).
 #include "common.hpp"
 #include "wave_topk.hpp"
@@ -76,8 +79,6 @@ __global__ __launch_bounds__(THREADS) void dense_scan_kernel(
     constexpr int GROUPS = kWave / G;  // rows per wave-load
     constexpr int RW = GROUPS * R;     // rows per wave iteration
     constexpr int WAVES = THREADS / kWave;
-    __shared__ float lds_s[WAVES * kListLen];
-    __shared__ uint32_t lds_r[WAVES * kListLen];
     __shared__ uint32_t lds_allow[FILTER ? 2048 : 1];  // 65536 source ids
 
     const int lane = lane_id();
@@ -91,25 +92,37 @@ __global__ __launch_bounds__(THREADS) void dense_scan_kernel(
 
     const f32x4 *__restrict__ ev = reinterpret_cast<const f32x4 *>(emb);
     const int64_t row_f4 = dim / 4;
-  for (int32_t qi = 0; qi < Q.n; ++qi) {
-    const float *__restrict__ query = Q.q[qi];
-    float *__restrict__ blk_score = Q.blk_s[qi];
-    uint32_t *__restrict__ blk_row = Q.blk_r[qi];
-    f32x4 q[CH];
-#pragma unroll
-    for (int c = 0; c < CH; ++c) q[c] = reinterpret_cast<const f32x4 *>(query)[c * G + sub];
-
+    // The queries of the launch are ONE stream of batches for a wave: the first batch of query i+1 (the same rows as the
+    // first batch of query i) is issued before the last batch of query i is reduced, so the wave never drains its
+    // loads at a query boundary (a drained boundary cost one exposed memory round trip, ~2 us, per query: 3.5 % of a
+    // 125k-row pass).
+    f32x4 q[CH], qn[CH];  // this query's slice and the next one's (fetched a whole query ahead)
     WaveTopK<float> top;
-    top.init(SCORES ? 1 : k);
-
-    // One batch = R row-groups of this wave: R*CH dwordx4 loads per lane.  The loop is software-pipelined over
-    // two register sets: the loads of batch i+1 are issued BEFORE batch i is reduced, so the wave always has
-    // loads in flight (a pure-read kernel of this geometry reaches 7.0-7.4 TB/s on MI355X:
-    // profiles/r01_hbm_read_ceiling.txt).
     struct Batch {
         f32x4 v[R][CH];
         uint32_t sid[R];
     };
+    auto fetch_query = [&](int32_t qi) {  // -> qn; clamped behind the last query (nobody uses that copy)
+        const float *__restrict__ query = Q.q[qi < Q.n ? qi : Q.n - 1];
+#pragma unroll
+        for (int c = 0; c < CH; ++c) qn[c] = reinterpret_cast<const f32x4 *>(query)[c * G + sub];
+    };
+    auto next_query = [&](int32_t qi) {  // qn -> q, and the fetch of the query after it: no wait at a boundary
+#pragma unroll
+        for (int c = 0; c < CH; ++c) q[c] = qn[c];
+        fetch_query(qi + 1);
+        top.init(SCORES ? 1 : k);
+    };
+    auto flush = [&](int32_t qi) {  // the wave's sorted list of query qi
+        if constexpr (!SCORES) {
+            Q.blk_s[qi][(blockIdx.x * WAVES + wave) * kListLen + lane] = top.s;
+            Q.blk_r[qi][(blockIdx.x * WAVES + wave) * kListLen + lane] = top.r;
+        }
+    };
+    // One batch = R row-groups of this wave: R*CH dwordx4 loads per lane.  The loop is software-pipelined over
+    // two register sets: the loads of batch i+1 are issued BEFORE batch i is reduced, so the wave always has
+    // loads in flight (a pure-read kernel of this geometry reaches 7.0-7.4 TB/s on MI355X:
+    // profiles/r01_hbm_read_ceiling.txt).
     auto issue = [&](int64_t base, Batch &bt) {
 #pragma unroll
         for (int r = 0; r < R; ++r) {
@@ -140,28 +153,55 @@ __global__ __launch_bounds__(THREADS) void dense_scan_kernel(
         }
     };
     const int64_t step = (int64_t)gridDim.x * WAVES * RW;
-    int64_t base = ((int64_t)blockIdx.x * WAVES + wave) * RW;
+    const int64_t base0 = ((int64_t)blockIdx.x * WAVES + wave) * RW;
+    if (base0 >= n_rows) {  // a wave without rows (tiny corpora): empty lists
+        top.init(1);
+        for (int32_t qi = 0; qi < Q.n; ++qi) flush(qi);
+        return;
+    }
+    int32_t qi = 0;
+    fetch_query(0);
+    next_query(0);
     Batch b0, b1;
-    if (base < n_rows) issue(base, b0);
-    while (base < n_rows) {
+    issue(base0, b0);
+    int64_t base = base0;
+    // Every step issues the NEXT batch unconditionally (behind the launch's last batch it re-reads the wave's first
+    // rows: 6 loads per wave and launch that nobody uses) and only then reduces the current one.  Unconditionally,
+    // because a load behind a branch leaves the compiler unsure how many loads are younger than the ones it is about
+    // to use, and it then waits for (nearly) all of them: `if (next < n_rows) issue(...)` made every step wait for the
+    // batch it had just issued (s_waitcnt vmcnt(2..0) instead of vmcnt(11..6)).  The rare block at a query boundary
+    // (two stores, a query reload) sits behind a scalar branch after the reduce.
+    for (;;) {
+        int32_t nq = qi;
         int64_t next = base + step;
-        if (next < n_rows) issue(next, b1);
-        reduce(base, b0);
-        base = next;
-        if (base >= n_rows) break;
-        next = base + step;
-        if (next < n_rows) issue(next, b0);
-        reduce(base, b1);
-        base = next;
-    }
-    if constexpr (!SCORES) {
-        block_merge(top, lds_s, lds_r, WAVES);
-        if (wave == 0) {
-            blk_score[blockIdx.x * kListLen + lane] = top.s;
-            blk_row[blockIdx.x * kListLen + lane] = top.r;
+        if (next >= n_rows) {
+            next = base0;
+            ++nq;
         }
+        issue(next, b1);
+        reduce(base, b0);
+        if (nq != qi) {
+            flush(qi);
+            if (nq >= Q.n) break;
+            qi = nq;
+            next_query(qi);
+        }
+        base = next;
+        next = base + step;
+        if (next >= n_rows) {
+            next = base0;
+            ++nq;
+        }
+        issue(next, b0);
+        reduce(base, b1);
+        if (nq != qi) {
+            flush(qi);
+            if (nq >= Q.n) break;
+            qi = nq;
+            next_query(qi);
+        }
+        base = next;
     }
-  }
 }
 
 // Any dim: one wave per row, scalar strided loads, query from global (L2).  Correctness path for
@@ -170,8 +210,6 @@ __global__ __launch_bounds__(kScanThreads) void dense_scan_topk_generic_kernel(
     const float *__restrict__ emb, const float *__restrict__ query, int64_t n_rows, int32_t dim, int32_t k,
     const uint16_t *__restrict__ src, const uint32_t *__restrict__ allow_bits, float *__restrict__ blk_score,
     uint32_t *__restrict__ blk_row, float *__restrict__ scores_out) {
-    __shared__ float lds_s[kScanWaves * kListLen];
-    __shared__ uint32_t lds_r[kScanWaves * kListLen];
     __shared__ uint32_t lds_allow[2048];
     const int lane = lane_id();
     const int wave = threadIdx.x / kWave;
@@ -194,11 +232,8 @@ __global__ __launch_bounds__(kScanThreads) void dense_scan_topk_generic_kernel(
         if (k > 0) top.offer_lanes(lane == kWave - 1 && ok && top.admits(acc, (uint32_t)row), acc, (uint32_t)row);
     }
     if (k > 0) {
-        block_merge(top, lds_s, lds_r, kScanWaves);
-        if (wave == 0) {
-            blk_score[blockIdx.x * kListLen + lane] = top.s;
-            blk_row[blockIdx.x * kListLen + lane] = top.r;
-        }
+        blk_score[(blockIdx.x * kScanWaves + wave) * kListLen + lane] = top.s;
+        blk_row[(blockIdx.x * kScanWaves + wave) * kListLen + lane] = top.r;
     }
 }
 
@@ -243,8 +278,8 @@ int launch_dense_scan_group(anrag_index *idx, hipStream_t st, const float *const
     for (int i = 0; i < kScanGroupMax; ++i) {
         const int j = i < n_queries ? i : 0;
         Q.q[i] = d_queries[j];
-        Q.blk_s[i] = idx->d_blk_score_f32 + (int64_t)sets[j] * kMaxScanBlocks * kListLen;
-        Q.blk_r[i] = idx->d_blk_row_a + (int64_t)sets[j] * kMaxScanBlocks * kListLen;
+        Q.blk_s[i] = idx->d_blk_score_f32 + (int64_t)sets[j] * kMaxScanLists * kListLen;
+        Q.blk_r[i] = idx->d_blk_row_a + (int64_t)sets[j] * kMaxScanLists * kListLen;
     }
     const float *d_query = d_queries[0];
     float *blk_s = Q.blk_s[0];

@@ -1,6 +1,6 @@
 // Query tail -- everything after the two streaming kernels, in ONE launch off the scan's critical path.
 //
-// K1 (dense scan) and K3 (BM25) each leave one sorted 64-entry list per workgroup in HBM.  This kernel
+// K1 (dense scan) leaves one sorted 64-entry list per WAVE, K3 (BM25) one per workgroup, in HBM.  This kernel
 //   1. merges the dense lists (waves 0-3) and the BM25 partition lists (waves 4-7) into per-modality top-k
 //      (the reference's argpartition+argsort, src/search_engine.py:83-87 / :236-243, finished),
 //   2. maps local rows to doc ids,
@@ -119,9 +119,9 @@ int launch_tail(anrag_index *idx, hipStream_t st, int set, bool use_dense, bool 
                 double w_dense, double w_bm25, double wrrf_k, int32_t top_n, anrag_candidate *d_out,
                 int32_t *d_count) {
     TailArgs a;
-    a.d_score = idx->d_blk_score_f32 + (int64_t)set * kMaxScanBlocks * kListLen;
-    a.d_row = idx->d_blk_row_a + (int64_t)set * kMaxScanBlocks * kListLen;
-    a.n_dense = use_dense ? dense_scan_grid(idx) : 0;
+    a.d_score = idx->d_blk_score_f32 + (int64_t)set * kMaxScanLists * kListLen;
+    a.d_row = idx->d_blk_row_a + (int64_t)set * kMaxScanLists * kListLen;
+    a.n_dense = use_dense ? dense_scan_lists(idx) : 0;
     a.dense_doc = idx->d_dense_doc;
     a.dense_base = idx->dense_doc_base;
     a.b_score = idx->d_blk_score_f64 + (int64_t)set * idx->n_parts * kListLen;
