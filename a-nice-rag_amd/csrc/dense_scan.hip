@@ -248,17 +248,20 @@ int dense_scan_grid(const anrag_index *idx) {
 template <int G, int CH>
 static void launch_scan(int grid, hipStream_t st, const anrag_index *idx, const ScanQueries &q, int32_t k,
                         const uint32_t *allow, float *scores_out) {
-    // 4-6 dwordx4 per lane per batch, two batches in flight = 8-12 loads per lane (768-d: R=1 6.07, R=2 7.05, R=3 6.96,
-    // R=4 6.86 TB/s; 1024-d: R=1 7.0, R=2 6.8 TB/s)
-    constexpr int R = CH >= 4 ? 1 : (CH >= 3 ? 2 : (CH == 2 ? 3 : 6));
-#define ANRAG_SCAN(F, S)                                                                                     \
-    dense_scan_kernel<G, CH, R, F, S><<<grid, kScanThreads, 0, st>>>(                                          \
+    // 6-8 dwordx4 per lane per batch, two batches in flight = 12-16 loads per lane.  With counted waits
+    // (profiles/r02_scan_sweep.txt, 1M rows): 768-d R=1 5.27, R=2 7.23, R=3 6.97, R=4 6.97 TB/s; 1024-d R=1 6.34,
+    // R=2 7.15, R=3 7.00 TB/s; 384-d R=1 5.22, R=2 7.08, R=3 6.86 TB/s.  Two workgroups per CU: 768-d 6.96 TB/s.
+    constexpr int R = CH >= 6 ? 1 : (CH >= 3 ? 2 : (CH == 2 ? 3 : 6));
+#define ANRAG_SCAN_R(F, S, RR)                                                                                \
+    dense_scan_kernel<G, CH, RR, F, S><<<grid, kScanThreads, 0, st>>>(                                         \
         idx->d_emb, q, idx->n_rows, idx->dim, k, idx->d_dense_src, allow, scores_out)
+#define ANRAG_SCAN(F, S) ANRAG_SCAN_R(F, S, R)
     if (scores_out) {
         if (allow) ANRAG_SCAN(true, true); else ANRAG_SCAN(false, true);
     } else {
         if (allow) ANRAG_SCAN(true, false); else ANRAG_SCAN(false, false);
     }
+#undef ANRAG_SCAN_R
 #undef ANRAG_SCAN
 }
 
