@@ -50,6 +50,7 @@ _SIGNATURES = {
     "anrag_index_sync": [_p],
     "anrag_dense_load": [_p, _p, _i64, _i32, _p, _p, _i64],
     "anrag_dense_search": [_p, _p, _i32, _i32, _p, _i32, _p, _p, _p],
+    "anrag_dense_search_f64": [_p, _p, _i32, _p, _i32, _p, _p, _p],
     "anrag_dense_search_device": [_p, _p, _i32, _i32, _p, _p],
     "anrag_dense_search_batch_device": [_p, _p, _i32, _i32, _p, _p, _p],
     "anrag_set_batched_precision": [_p, _i32],

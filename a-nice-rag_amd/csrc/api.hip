@@ -219,6 +219,7 @@ static void free_host_slots(anrag_index *idx);
 
 static void free_dense(anrag_index *idx) {
     free_batched(idx);
+    dev_free(idx, idx->d_dense_scores_f64, idx->n_rows);
     dev_free(idx, idx->d_emb, idx->n_rows * idx->dim);
     dev_free(idx, idx->d_dense_src, idx->n_rows);
     dev_free(idx, idx->d_dense_doc, idx->n_rows);
@@ -237,7 +238,8 @@ int anrag_index_destroy(anrag_index *idx) {
         (void)drain_profile(idx);
         free_dense(idx);
         free_bm25(idx);
-        void *ptrs[] = {idx->d_blk_score_f32, idx->d_blk_row_a, idx->d_blk_score_f64, idx->d_blk_row_b, idx->d_query,
+        void *ptrs[] = {idx->d_query_f64,
+                        idx->d_blk_score_f32, idx->d_blk_row_a, idx->d_blk_score_f64, idx->d_blk_row_b, idx->d_query,
                         idx->d_allow_a,       idx->d_allow_b,   idx->d_terms,         idx->d_cand_a,
                         idx->d_cand_out,      idx->d_scores_f64, idx->d_sort_tmp,     idx->d_sort_buf};
         for (void *p : ptrs)
@@ -357,6 +359,22 @@ int anrag_dense_search_device(anrag_index *idx, const float *d_queries, int32_t 
         if (rc) return rc;
     }
     return ANRAG_OK;
+}
+
+int anrag_dense_search_f64(anrag_index *idx, const double *query, int32_t k, const uint8_t *allow_source,
+                           int32_t n_sources, int64_t *out_doc, double *out_score, int32_t *out_count) {
+    ANRAG_ENTER(idx);
+    ANRAG_REQUIRE(idx->d_emb != nullptr, "dense search before anrag_dense_load");
+    ANRAG_REQUIRE(query && out_doc && out_score && out_count, "NULL operand");
+    ANRAG_REQUIRE(k > 0, "k must be positive");
+    ANRAG_REQUIRE(!(allow_source && !idx->d_dense_src), "a source filter needs source ids (anrag_dense_load)");
+    hipStream_t st = idx->primary;
+    int rc;
+    if ((rc = settle_pipeline(idx))) return rc;
+    const uint32_t *d_allow = nullptr;
+    uint32_t *h_bits = reinterpret_cast<uint32_t *>(idx->h_pinned);
+    if ((rc = stage_allow(idx, st, allow_source, n_sources, idx->d_allow_a, h_bits, &d_allow))) return rc;
+    return dense_search_f64(idx, st, query, k, d_allow, out_doc, out_score, out_count);
 }
 
 int anrag_dense_scores(anrag_index *idx, const float *query, float *out_scores) {

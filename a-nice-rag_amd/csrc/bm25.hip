@@ -511,7 +511,10 @@ int bm25_load(anrag_index *idx, const int64_t *indptr, int64_t n_terms, const in
     ANRAG_REQUIRE(n_docs > 0 && n_docs < 0x7FFFFFFF, "n_docs %lld out of range (1 .. 2^31-2 per shard)",
                   (long long)n_docs);
     ANRAG_REQUIRE(indptr[0] == 0, "indptr[0] must be 0");
-    ANRAG_REQUIRE(avgdl > 0.0, "avgdl must be positive");
+    ANRAG_REQUIRE(avgdl > 0.0 && avgdl < __builtin_huge_val(), "avgdl must be positive and finite");
+    ANRAG_REQUIRE(k1 == k1 && b == b, "k1 / b must be numbers");
+    for (int64_t t = 0; t < n_terms; ++t)  // a non-finite idf would make scores NaN / inf, which K3's order excludes
+        ANRAG_REQUIRE(idf[t] - idf[t] == 0.0, "idf of term %lld is not finite", (long long)t);
     const int64_t n_postings = indptr[n_terms];
     for (int64_t t = 0; t < n_terms; ++t) {
         ANRAG_REQUIRE(indptr[t + 1] >= indptr[t], "indptr not monotone at term %lld", (long long)t);

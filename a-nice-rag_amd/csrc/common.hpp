@@ -124,6 +124,8 @@ struct anrag_index {
     int64_t pinned_bytes = 0;
     float *d_scores_f32 = nullptr;      // full score arrays for k > ANRAG_FUSED_K_MAX
     double *d_scores_f64 = nullptr;
+    double *d_dense_scores_f64 = nullptr;  // fp64-query dense path: n_rows scores
+    double *d_query_f64 = nullptr;
     void *d_sort_tmp = nullptr;
     int64_t sort_tmp_bytes = 0;
     void *d_sort_buf = nullptr;
@@ -205,6 +207,11 @@ int launch_tail(anrag_index *idx, hipStream_t st, int set, bool use_dense, bool 
 // K1 + tail on one stream (set 0)
 int launch_dense_topk(anrag_index *idx, hipStream_t stream, const float *d_query, int32_t k,
                       const uint32_t *d_allow_bits, anrag_candidate *d_out, float *d_scores_out);
+// fp64 query: every row's fp64 dot product (dense_scan.hip); selection by dense_search_f64 (sort_select.hip)
+int launch_dense_scores_f64(anrag_index *idx, hipStream_t st, const double *d_query, const uint32_t *d_allow_bits,
+                            double *d_scores_out);
+int dense_search_f64(anrag_index *idx, hipStream_t st, const double *h_query, int32_t k, const uint32_t *d_allow_bits,
+                     int64_t *out_doc, double *out_score, int32_t *out_count);
 // K2: up to 256 queries per pass on the fp32 matrix cores (dense_batched.hip)
 bool batched_path_applies(const anrag_index *idx, int32_t n_queries, int32_t k);
 int launch_dense_batched(anrag_index *idx, hipStream_t st, const float *d_queries, int32_t nq, int32_t k,

@@ -38,7 +38,8 @@ __device__ __forceinline__ void batched_tile_epilogue(f32x16 (&acc)[TI][2], int6
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int64_t wr = tile * (2 * TI * 32) + rw * (TI * 32) + ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                const float s = acc[ti][tj][r];
+                float s = acc[ti][tj][r];
+                if (s != s) s = __builtin_huge_valf();  // NaN ranks first, as in K1 (and in numpy)
                 if constexpr (SAMPLE) {
                     if (wr < n_work) {
                         bool ok = true;

@@ -56,6 +56,12 @@ __device__ __forceinline__ float group_sum(float v) {
     return v;
 }
 
+// A NaN dot product (a corrupt row, a NaN in the query) ranks FIRST, as it does in the reference: numpy's
+// argpartition / argsort order NaN above every number (src/search_engine.py:83-87).  It is carried as +inf from here
+// on (and reported as +inf): every comparison downstream stays an ordinary float comparison.
+__device__ __forceinline__ float nan_first(float v) { return v != v ? __builtin_huge_valf() : v; }
+__device__ __forceinline__ double nan_first(double v) { return v != v ? __builtin_huge_val() : v; }
+
 // G  lanes per row (64,32,16); dim % (4*G) == 0
 // CH float4 chunks per lane per row (dim / (4*G)), compile-time so the query sits in registers
 // R  row-groups in flight per wave iteration
@@ -141,7 +147,7 @@ __global__ __launch_bounds__(THREADS) void dense_scan_kernel(
             float acc = 0.f;
 #pragma unroll
             for (int c = 0; c < CH; ++c) acc = dot4(bt.v[r][c], q[c], acc);
-            acc = group_sum<G>(acc);
+            acc = nan_first(group_sum<G>(acc));
             bool ok = row < n_rows;
             if constexpr (FILTER) ok = ok && source_ok(lds_allow, bt.sid[r]);
             if constexpr (SCORES) {
@@ -225,7 +231,7 @@ __global__ __launch_bounds__(kScanThreads) void dense_scan_topk_generic_kernel(
         const float *p = emb + row * dim;
         float acc = 0.f;
         for (int c = lane; c < dim; c += kWave) acc = __builtin_fmaf(p[c], query[c], acc);
-        acc = group_sum<kWave>(acc);  // total lands in lane 63
+        acc = nan_first(group_sum<kWave>(acc));  // total lands in lane 63
         bool ok = true;
         if (filtered) ok = source_ok(lds_allow, src[row]);
         if (scores_out != nullptr && lane == kWave - 1) scores_out[row] = ok ? acc : neg_inf<float>();
@@ -235,6 +241,59 @@ __global__ __launch_bounds__(kScanThreads) void dense_scan_topk_generic_kernel(
         blk_score[(blockIdx.x * kScanWaves + wave) * kListLen + lane] = top.s;
         blk_row[(blockIdx.x * kScanWaves + wave) * kListLen + lane] = top.r;
     }
+}
+
+// fp64 query (the reference's text path: the embedding API returns float64, and np.dot then promotes the fp32 matrix and
+// scores in fp64, src/search_engine.py:157, :129): every row's dot product accumulated in fp64 from the fp32 rows
+// (exact in fp64) and the fp64 query -- all N scores; selection is the score-array sort (sort_select.hip).  One wave
+// per row, 16-byte loads when the rows allow it.  HBM-bound like K1 but not tuned like it: this path answers one
+// query behind a remote embedding call.
+__global__ __launch_bounds__(kScanThreads) void dense_scores_f64_kernel(
+    const float *__restrict__ emb, const double *__restrict__ query, int64_t n_rows, int32_t dim,
+    const uint16_t *__restrict__ src, const uint32_t *__restrict__ allow_bits, double *__restrict__ scores_out) {
+    __shared__ uint32_t lds_allow[2048];
+    const int lane = lane_id();
+    const int wave = threadIdx.x / kWave;
+    const bool filtered = allow_bits != nullptr;
+    if (filtered) {
+        for (int i = threadIdx.x; i < 2048; i += kScanThreads) lds_allow[i] = allow_bits[i];
+        __syncthreads();
+    }
+    const int64_t total_waves = (int64_t)gridDim.x * kScanWaves;
+    const bool vec = dim % 4 == 0;
+    for (int64_t row = (int64_t)blockIdx.x * kScanWaves + wave; row < n_rows; row += total_waves) {
+        const float *p = emb + row * dim;
+        double acc = 0.0;
+        if (vec) {
+            for (int c = lane * 4; c < dim; c += kWave * 4) {
+                const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(p + c));
+                acc = __builtin_fma((double)v.x, query[c], acc);
+                acc = __builtin_fma((double)v.y, query[c + 1], acc);
+                acc = __builtin_fma((double)v.z, query[c + 2], acc);
+                acc = __builtin_fma((double)v.w, query[c + 3], acc);
+            }
+        } else {
+            for (int c = lane; c < dim; c += kWave) acc = __builtin_fma((double)p[c], query[c], acc);
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, kWave);
+        acc = nan_first(acc);
+        bool ok = true;
+        if (filtered) ok = source_ok(lds_allow, src[row]);
+        if (lane == 0) scores_out[row] = ok ? acc : neg_inf<double>();
+    }
+}
+
+int launch_dense_scores_f64(anrag_index *idx, hipStream_t st, const double *d_query, const uint32_t *d_allow_bits,
+                            double *d_scores_out) {
+    const uint32_t *allow = (idx->d_dense_src != nullptr) ? d_allow_bits : nullptr;
+    const int64_t need = (idx->n_rows + kScanWaves - 1) / kScanWaves;
+    const int64_t cap = (int64_t)idx->n_cus * 8;  // 32 waves per CU: latency hiding by occupancy, no software pipeline
+    LaunchTimer t(idx, ANRAG_KERNEL_DENSE_SCAN, st);
+    dense_scores_f64_kernel<<<(unsigned)(need < cap ? need : cap), kScanThreads, 0, st>>>(
+        idx->d_emb, d_query, idx->n_rows, idx->dim, idx->d_dense_src, allow, d_scores_out);
+    ANRAG_HIP(hipGetLastError());
+    return ANRAG_OK;
 }
 
 int dense_scan_grid(const anrag_index *idx) {

@@ -118,6 +118,25 @@ int dense_search_large_k(anrag_index *idx, hipStream_t st, const float *h_querie
     return ANRAG_OK;
 }
 
+// fp64 query: fp64 score array + the same sort, for any k (one query at a time: the reference's text path)
+int dense_search_f64(anrag_index *idx, hipStream_t st, const double *h_query, int32_t k, const uint32_t *d_allow_bits,
+                     int64_t *out_doc, double *out_score, int32_t *out_count) {
+    const int64_t n = idx->n_rows;
+    if (!idx->d_dense_scores_f64) {
+        ANRAG_HIP(hipMalloc(reinterpret_cast<void **>(&idx->d_dense_scores_f64), (size_t)n * sizeof(double)));
+        idx->hbm_bytes += n * 8;
+    }
+    if (!idx->d_query_f64) ANRAG_HIP(hipMalloc(reinterpret_cast<void **>(&idx->d_query_f64), 65536 * sizeof(double)));
+    ANRAG_HIP(hipMemcpyAsync(idx->d_query_f64, h_query, (size_t)idx->dim * sizeof(double), hipMemcpyHostToDevice, st));
+    int rc = launch_dense_scores_f64(idx, st, idx->d_query_f64, d_allow_bits, idx->d_dense_scores_f64);
+    if (rc) return rc;
+    const int64_t have = std::min<int64_t>(k, n);
+    anrag_candidate *d_c = nullptr;
+    if ((rc = sort_scores<double>(idx, st, idx->d_dense_scores_f64, n, have, idx->d_dense_doc, idx->dense_doc_base, &d_c)))
+        return rc;
+    return fetch_ranked<double>(st, d_c, have, k, out_doc, out_score, out_count);
+}
+
 int bm25_search_large_k(anrag_index *idx, hipStream_t st, const int32_t *d_terms, int32_t n_terms, int32_t k,
                         const uint32_t *d_allow_bits, int64_t *out_doc, double *out_score, int32_t *out_count) {
     const int64_t n = idx->n_docs;

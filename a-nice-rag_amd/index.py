@@ -106,6 +106,19 @@ class Index:
                                                doc.ctypes.data, score.ctypes.data, count.ctypes.data))
         return doc, score, count
 
+    def dense_search_f64(self, query, k: int, allow_source=None):
+        """One float64 query, scored in fp64 like numpy scores it (`anrag_dense_search_f64`).
+        -> (doc [k] int64, score [k] float64, count)."""
+        q = np.ascontiguousarray(query, dtype=np.float64).reshape(-1)
+        assert q.size == self.dim, f"query dim {q.size} != index dim {self.dim}"
+        allow, ns = _allow_bytes(allow_source)
+        doc = np.empty(k, np.int64)
+        score = np.empty(k, np.float64)
+        count = np.zeros(1, np.int32)
+        nat.check(self._lib.anrag_dense_search_f64(self.handle, q.ctypes.data, int(k), nat.ptr(allow), ns,
+                                                   doc.ctypes.data, score.ctypes.data, count.ctypes.data))
+        return doc, score, int(count[0])
+
     def set_batched_precision(self, mode: str = "f32") -> None:
         """"f32": exact f32 MFMA (default).  "bf16x3": split-precision products on the bf16 matrix cores (scores within
         ~3e-5 of f32 for unit-norm vectors)."""

@@ -6,8 +6,9 @@ search_engine.py:94-98, :144-146, :267-269, :291-293) so that query_rag_retrieva
 retrieval_eval.py-shaped callers run unchanged.  What differs, by design:
   * ties are ordered (score desc, row asc); the reference leaves them to numpy's unstable
     argpartition/argsort (its filtered BM25 path already is row-ascending: a stable sort);
-  * dense scores are fp32 products accumulated in fp32 (within 1e-4 of numpy's BLAS result); an
-    fp64 query (the text path, :157) is rounded to fp32 first;
+  * dense scores of an fp32 query are fp32 products accumulated in fp32 (within 1e-4 of numpy's BLAS result); an
+    fp64 query (the text path, :157) is scored in fp64 like numpy scores it (`anrag_dense_search_f64`);
+  * a NaN dense score ranks first, as numpy ranks it, and is reported as +inf;
   * a missing HIP library or GPU raises `AnragError` instead of being swallowed: there is no CPU path.
 """
 from __future__ import annotations
@@ -119,12 +120,12 @@ class SearchEngine:
         if q.ndim == 2 and q.shape[0] != 1:
             # the reference flattens a B x N score matrix and then fails on iloc (:81, :89): same outcome
             raise ValueError("batched query_embedding: use similarity_search_batch")
+        if q.dtype == np.float64:  # the text path (:157): numpy promotes and scores in fp64 (:129) -- so does the device
+            doc, score, n = h.index.dense_search_f64(q.reshape(-1), int(similarity_k), allow)
+            return h, doc[:n], score[:n]
         doc, score, count = h.index.dense_search(q.reshape(-1), int(similarity_k), allow)
         n = int(count[0])
-        sims = score[0, :n]
-        if q.dtype == np.float64:
-            sims = sims.astype(np.float64)  # numpy would have promoted (:81)
-        return h, doc[0, :n], sims
+        return h, doc[0, :n], score[0, :n]
 
     def similarity_search_with_embedding(self, query_embedding: np.ndarray, df: pd.DataFrame,
                                          model_name: str = "voyage-3-large", similarity_k: int = 25,

@@ -25,6 +25,9 @@
  *     caller (a global id space shared by the dense rows and the BM25 rows, so
  *     that fusion can run on ids as the reference fuses on chunk-id strings,
  *     search_engine.py:27-32).  Strings never cross the boundary.
+ *   - a NaN dense score (a corrupt row, a NaN in the query) ranks FIRST, as numpy's
+ *     argpartition / argsort rank it (search_engine.py:83-87); it is reported as
+ *     +inf.  BM25 scores cannot be NaN: anrag_bm25_load rejects non-finite idf / avgdl.
  *   - ordering rule everywhere: score descending, then ROW ascending (rows are
  *     what the reference's tie behaviour is stated in: its filtered BM25 path is
  *     a stable sort = low row first, :233; its numpy paths leave ties
@@ -127,6 +130,17 @@ int anrag_dense_load(anrag_index *idx, const float *embeddings, int64_t n_rows, 
 int anrag_dense_search(anrag_index *idx, const float *queries, int32_t n_queries, int32_t k,
                        const uint8_t *allow_source, int32_t n_sources, int64_t *out_doc,
                        float *out_score, int32_t *out_count);
+
+/* The same for ONE fp64 query: the reference's text path gets float64 from the
+ * embedding API and np.dot then promotes the fp32 matrix and scores in fp64
+ * (search_engine.py:157, :129).  Rows stay fp32 in HBM; every dot product is
+ * accumulated in fp64 (fp32 values are exact in fp64), selection by sorting the
+ * fp64 score array: any k.  out_score: fp64.  (The fp32 entry points round an
+ * fp64 query to fp32 first -- inside the 1e-4 bar, not the reference's bits;
+ * the Python shim calls this one when it is handed a float64 query.) */
+int anrag_dense_search_f64(anrag_index *idx, const double *query, int32_t k,
+                           const uint8_t *allow_source, int32_t n_sources, int64_t *out_doc,
+                           double *out_score, int32_t *out_count);
 
 /* Same, all operands in HBM, no host sync: d_out is n_queries x k
  * anrag_candidate.  The scans run back to back on the primary stream, each

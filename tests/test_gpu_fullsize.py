@@ -24,7 +24,7 @@ def world():
 
     dev = torch.device("cuda", 0)
     E = synth.dense_corpus(N, D, 1234, dev)
-    Q, planted = synth.dense_queries(E, 32, 4321)
+    Q, planted = synth.dense_queries(E, 256, 4321)
     idx = Index(0)
     torch.cuda.synchronize()  # device-pointer operands must be complete before the library copies them
     idx.dense_load((E.data_ptr(), N, D))
@@ -43,7 +43,7 @@ def test_dense_kernels_agree_at_full_size(world):
     qh = Q.cpu().numpy()
     k = 10
     d1, s1, c1 = idx.dense_search(qh[:8], k)          # 8 < 16 queries: K1, one scan each
-    d2, s2, c2 = idx.dense_search(qh, k)              # 32 queries: K2, one MFMA pass
+    d2, s2, c2 = idx.dense_search(qh, k)              # BASELINE configs[3]: 256 queries, ONE full-width MFMA pass
     ref = (Q @ E.T).topk(k, dim=1)
     ri, rv = ref.indices.cpu().numpy(), ref.values.cpu().numpy()
     assert np.all(c1 == k) and np.all(c2 == k)
@@ -53,6 +53,83 @@ def test_dense_kernels_agree_at_full_size(world):
     assert np.all(np.diff(s1, axis=1) <= 0) and np.all(np.diff(s2, axis=1) <= 0)
     again = idx.dense_search(qh[:8], k)
     assert np.array_equal(again[0], d1) and np.array_equal(again[1], s1)     # bit-identical on repeat
+    # the opt-in split-precision arithmetic (bf16 x 3 products): the same 256 x 1M pass inside the 1e-4 bar
+    from helpers import assert_ranking_matches
+    idx.set_batched_precision("bf16x3")
+    try:
+        d3, s3, c3 = idx.dense_search(qh, k)
+    finally:
+        idx.set_batched_precision("f32")
+    assert np.all(c3 == k)
+    for i in range(len(qh)):
+        assert_ranking_matches(ri[i], rv[i], d3[i], s3[i], 1e-4, None, f"bf16x3 query {i}")
+    assert np.mean(d3 == ri) > 0.999  # and in practice the same ids: the split products are ~1e-6 from f32
+
+
+def test_c2_100k_x768_top10_vs_oracle(world):
+    """BASELINE configs[1] at its exact size: 100,000 x 768, dense-only top-10 at batch = 1, against the CPU oracle
+    (one np.dot over 0.3 GB per query) -- ids equal, scores within 1e-4."""
+    from oracle import ref_search
+    from helpers import assert_ranking_matches
+    from anrag.index import Index
+
+    E, Q = world["E"], world["Q"]
+    n = 100_000
+    e_host = E[:n].cpu().numpy()
+    with Index(0) as sub:
+        sub.dense_load((E.data_ptr(), n, D))  # the first 100k rows of the same corpus
+        for qi in (0, 1, 2, 3, 100, 255):
+            q = Q[qi].cpu().numpy()
+            want = ref_search.dense_scores(q, e_host)
+            order = ref_search.canonical_topk(want, 10)
+            doc, score, cnt = sub.dense_search(q, 10)
+            assert cnt[0] == 10
+            assert_ranking_matches(order, want[order], doc[0], score[0], 1e-4, want, f"C2 query {qi}")
+
+
+def test_c5_rank_shape_1m_x1024_hybrid():
+    """BASELINE configs[4] as ONE rank sees it: a 1M x 1024 shard (4.1 GB) with its postings, hybrid.  Size-independent
+    properties: K1 == torch.topk on the device's own data, the fused answer == oracle WRRF of the device's own
+    per-modality lists, planted neighbours first, the candidate payload == the two lists."""
+    import torch
+    from oracle import ref_search
+    from anrag import _native as nat, synth
+    from anrag.index import Index
+
+    dev = torch.device("cuda", 0)
+    n, d, k = 1_000_000, 1024, 25
+    E = synth.dense_corpus(n, d, 99, dev, row_lo=3_000_000)        # rows [3M, 4M) of an 8M-row corpus
+    Q, planted = synth.dense_queries(E, 8, 17)
+    post = synth.bm25_postings(n, 200_000, 55, dev, doc_lo=3_000_000)
+    idf = synth.bm25_idf(post["df"].cpu().numpy(), n)
+    terms = synth.bm25_queries(post, 8, 19)
+    torch.cuda.synchronize()
+    lib = nat.load_library()
+    with Index(0) as idx:
+        idx.dense_load((E.data_ptr(), n, d), doc_id_base=3_000_000)
+        idx.bm25_load(post["indptr"], (post["post_doc"].data_ptr(), post["post_doc"].numel()),
+                      (post["post_tf"].data_ptr(), post["post_tf"].numel()), idf, post["doc_len"],
+                      post["total_len"] / n, 1.7, 0.83, doc_id_base=3_000_000)
+        ref = (Q @ E.T).topk(k, dim=1)
+        out = torch.zeros((2 * k, 2), dtype=torch.int64, device=dev)
+        T = torch.full((16,), -1, dtype=torch.int32, device=dev)
+        for qi in range(8):
+            q = Q[qi].cpu().numpy()
+            doc, score, cnt = idx.dense_search(q, k)
+            assert cnt[0] == k and (doc[0] - 3_000_000).tolist() == ref.indices[qi].cpu().tolist()
+            assert np.max(np.abs(score[0] - ref.values[qi].cpu().numpy())) <= 1e-4
+            assert doc[0, 0] - 3_000_000 == int(planted[qi])
+            bl = idx.bm25_search(terms[qi], k)[0]
+            ids, scores = idx.hybrid_search(q, terms[qi], k, 5.0, 1.0, 40, 10)
+            want = ref_search.weighted_reciprocal_rank_fusion([(doc[0].tolist(), "d"), (bl.tolist(), "b")],
+                                                              {"d": 5.0, "b": 1.0}, 40)[:10]
+            assert ids.tolist() == [i for i, _ in want] and scores.tolist() == [s for _, s in want]
+            T[: len(terms[qi])] = torch.from_numpy(np.asarray(terms[qi], np.int32)).to(dev)
+            nat.check(lib.anrag_hybrid_candidates_device(idx.handle, Q[qi].data_ptr(), T.data_ptr(), len(terms[qi]), k,
+                                                         None, None, out.data_ptr()))
+            idx.sync()
+            rec = out.cpu().numpy()
+            assert rec[:k, 1].tolist() == doc[0].tolist() and rec[k:, 1].tolist() == bl.tolist()
 
 
 def test_sharded_merge_equals_whole(world):
