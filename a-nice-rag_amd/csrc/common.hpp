@@ -188,6 +188,7 @@ int drain_profile(anrag_index *idx);
 // ---- kernel launchers (each enqueues on `stream`, never syncs)
 int dense_scan_grid(const anrag_index *idx);
 inline int dense_scan_lists(const anrag_index *idx) { return dense_scan_grid(idx) * kScanWaves; }
+int dense_scan_vgprs(const anrag_index *idx);  // registers of the scan kernel this index's dimension runs
 // K1 alone: one sorted list per workgroup into block-list set `set` (or every score into d_scores_out, k = 0)
 int launch_dense_scan(anrag_index *idx, hipStream_t stream, const float *d_query, int32_t k,
                       const uint32_t *d_allow_bits, float *d_scores_out, int set);

@@ -102,21 +102,39 @@ __global__ __launch_bounds__(THREADS) void dense_scan_kernel(
     // first batch of query i) is issued before the last batch of query i is reduced, so the wave never drains its
     // loads at a query boundary (a drained boundary cost one exposed memory round trip, ~2 us, per query: 3.5 % of a
     // 125k-row pass).
-    f32x4 q[CH], qn[CH];  // this query's slice and the next one's (fetched a whole query ahead)
+    // this query's slice and, when registers allow (CH <= 3: a scan wave must stay within 128 VGPRs to share its SIMD
+    // with four K3 waves of 96), the next one's, fetched a whole query ahead
+    constexpr bool PREFETCH_Q = CH <= 3;
+    f32x4 q[CH], qn[PREFETCH_Q ? CH : 1];
     WaveTopK<float> top;
+    // Long rows (D >= 3072) are streamed in two halves: a batch is HALF a row-group (6-8 loads per lane, the same
+    // 12-16 in flight as the other shapes), set b0 always the first half, b1 the second, the partial dot product
+    // carried between them.  Whole-row batches of 12-16 loads needed 254+ VGPRs (two sets + the query slice); halves
+    // need ~130, and 24-32 loads in flight per lane were past the optimum anyway (82.6 % at 3072-d).
+    constexpr int SPLIT = CH >= 12 ? 2 : 1;
+    constexpr int CHB = CH / SPLIT;
+    static_assert(CH % SPLIT == 0 && (SPLIT == 1 || R == 1), "long rows: one row-group per batch, two halves");
     struct Batch {
-        f32x4 v[R][CH];
+        f32x4 v[R][CHB];
         uint32_t sid[R];
     };
     auto fetch_query = [&](int32_t qi) {  // -> qn; clamped behind the last query (nobody uses that copy)
-        const float *__restrict__ query = Q.q[qi < Q.n ? qi : Q.n - 1];
+        if constexpr (PREFETCH_Q) {
+            const float *__restrict__ query = Q.q[qi < Q.n ? qi : Q.n - 1];
 #pragma unroll
-        for (int c = 0; c < CH; ++c) qn[c] = reinterpret_cast<const f32x4 *>(query)[c * G + sub];
+            for (int c = 0; c < CH; ++c) qn[c] = reinterpret_cast<const f32x4 *>(query)[c * G + sub];
+        }
     };
     auto next_query = [&](int32_t qi) {  // qn -> q, and the fetch of the query after it: no wait at a boundary
+        if constexpr (PREFETCH_Q) {
 #pragma unroll
-        for (int c = 0; c < CH; ++c) q[c] = qn[c];
-        fetch_query(qi + 1);
+            for (int c = 0; c < CH; ++c) q[c] = qn[c];
+            fetch_query(qi + 1);
+        } else {
+            const float *__restrict__ query = Q.q[qi];
+#pragma unroll
+            for (int c = 0; c < CH; ++c) q[c] = reinterpret_cast<const f32x4 *>(query)[c * G + sub];
+        }
         top.init(SCORES ? 1 : k);
     };
     auto flush = [&](int32_t qi) {  // the wave's sorted list of query qi
@@ -129,33 +147,56 @@ __global__ __launch_bounds__(THREADS) void dense_scan_kernel(
     // two register sets: the loads of batch i+1 are issued BEFORE batch i is reduced, so the wave always has
     // loads in flight (a pure-read kernel of this geometry reaches 7.0-7.4 TB/s on MI355X:
     // profiles/r01_hbm_read_ceiling.txt).
-    auto issue = [&](int64_t base, Batch &bt) {
+    auto issue = [&](int64_t base, Batch &bt, int half = 0) {
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const int64_t row = base + r * GROUPS + grp;
             const int64_t rc = row < n_rows ? row : n_rows - 1;  // clamp: tail lanes re-read the last row
             if constexpr (FILTER) bt.sid[r] = src[rc];           // issued ahead of the row data
-            const f32x4 *p = ev + rc * row_f4 + sub;
+            const f32x4 *p = ev + rc * row_f4 + sub + half * CHB * G;
 #pragma unroll
-            for (int c = 0; c < CH; ++c) bt.v[r][c] = __builtin_nontemporal_load(p + c * G);
+            for (int c = 0; c < CHB; ++c) bt.v[r][c] = __builtin_nontemporal_load(p + c * G);
+        }
+    };
+    float part[R];        // SPLIT == 2: the first half's partial dot products
+    uint32_t part_sid[R];
+    auto finish_row = [&](int64_t row, float acc, uint32_t sid) {
+        acc = nan_first(group_sum<G>(acc));
+        bool ok = row < n_rows;
+        if constexpr (FILTER) ok = ok && source_ok(lds_allow, sid);
+        if constexpr (SCORES) {
+            if (leader && row < n_rows) scores_out[row] = ok ? acc : neg_inf<float>();
+        } else {
+            const uint32_t r32 = (uint32_t)row;
+            top.offer_lanes(leader && ok && top.admits(acc, r32), acc, r32);
         }
     };
     auto reduce = [&](int64_t base, const Batch &bt) {
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            const int64_t row = base + r * GROUPS + grp;
             float acc = 0.f;
 #pragma unroll
-            for (int c = 0; c < CH; ++c) acc = dot4(bt.v[r][c], q[c], acc);
-            acc = nan_first(group_sum<G>(acc));
-            bool ok = row < n_rows;
-            if constexpr (FILTER) ok = ok && source_ok(lds_allow, bt.sid[r]);
-            if constexpr (SCORES) {
-                if (leader && row < n_rows) scores_out[row] = ok ? acc : neg_inf<float>();
-            } else {
-                const uint32_t r32 = (uint32_t)row;
-                top.offer_lanes(leader && ok && top.admits(acc, r32), acc, r32);
-            }
+            for (int c = 0; c < CHB; ++c) acc = dot4(bt.v[r][c], q[c], acc);
+            finish_row(base + r * GROUPS + grp, acc, bt.sid[r]);
+        }
+    };
+    auto reduce_first_half = [&](const Batch &bt) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            float acc = 0.f;
+#pragma unroll
+            for (int c = 0; c < CHB; ++c) acc = dot4(bt.v[r][c], q[c], acc);
+            part[r] = acc;
+            part_sid[r] = bt.sid[r];
+        }
+    };
+    auto reduce_second_half = [&](int64_t base, const Batch &bt) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            float acc = part[r];
+#pragma unroll
+            for (int c = 0; c < CHB; ++c) acc = dot4(bt.v[r][c], q[CHB + c], acc);
+            finish_row(base + r * GROUPS + grp, acc, part_sid[r]);
         }
     };
     const int64_t step = (int64_t)gridDim.x * WAVES * RW;
@@ -177,6 +218,28 @@ __global__ __launch_bounds__(THREADS) void dense_scan_kernel(
     // to use, and it then waits for (nearly) all of them: `if (next < n_rows) issue(...)` made every step wait for the
     // batch it had just issued (s_waitcnt vmcnt(2..0) instead of vmcnt(11..6)).  The rare block at a query boundary
     // (two stores, a query reload) sits behind a scalar branch after the reduce.
+    if constexpr (SPLIT == 2) {
+        for (;;) {
+            issue(base, b1, 1);  // the second half of the same rows
+            reduce_first_half(b0);
+            int32_t nq = qi;
+            int64_t next = base + step;
+            if (next >= n_rows) {
+                next = base0;
+                ++nq;
+            }
+            issue(next, b0, 0);  // the first half of the next rows
+            reduce_second_half(base, b1);
+            if (nq != qi) {
+                flush(qi);
+                if (nq >= Q.n) break;
+                qi = nq;
+                next_query(qi);
+            }
+            base = next;
+        }
+        return;
+    }
     for (;;) {
         int32_t nq = qi;
         int64_t next = base + step;
@@ -304,24 +367,71 @@ int dense_scan_grid(const anrag_index *idx) {
     return grid;
 }
 
+// row-groups per batch: 6-8 dwordx4 per lane per batch, two batches in flight = 12-16 loads per lane.  With counted
+// waits (profiles/r02_scan_sweep.txt, 1M rows): 768-d R=1 5.27, R=2 7.23, R=3 6.97, R=4 6.97 TB/s; 1024-d R=1 6.34,
+// R=2 7.15, R=3 7.00 TB/s; 384-d R=1 5.22, R=2 7.08, R=3 6.86 TB/s.  Two workgroups per CU: 768-d 6.96 TB/s.
+template <int CH>
+constexpr int scan_r() { return CH >= 6 ? 1 : (CH >= 3 ? 2 : (CH == 2 ? 3 : 6)); }
+
 template <int G, int CH>
-static void launch_scan(int grid, hipStream_t st, const anrag_index *idx, const ScanQueries &q, int32_t k,
-                        const uint32_t *allow, float *scores_out) {
-    // 6-8 dwordx4 per lane per batch, two batches in flight = 12-16 loads per lane.  With counted waits
-    // (profiles/r02_scan_sweep.txt, 1M rows): 768-d R=1 5.27, R=2 7.23, R=3 6.97, R=4 6.97 TB/s; 1024-d R=1 6.34,
-    // R=2 7.15, R=3 7.00 TB/s; 384-d R=1 5.22, R=2 7.08, R=3 6.86 TB/s.  Two workgroups per CU: 768-d 6.96 TB/s.
-    constexpr int R = CH >= 6 ? 1 : (CH >= 3 ? 2 : (CH == 2 ? 3 : 6));
-#define ANRAG_SCAN_R(F, S, RR)                                                                                \
-    dense_scan_kernel<G, CH, RR, F, S><<<grid, kScanThreads, 0, st>>>(                                         \
-        idx->d_emb, q, idx->n_rows, idx->dim, k, idx->d_dense_src, allow, scores_out)
-#define ANRAG_SCAN(F, S) ANRAG_SCAN_R(F, S, R)
-    if (scores_out) {
-        if (allow) ANRAG_SCAN(true, true); else ANRAG_SCAN(false, true);
-    } else {
-        if (allow) ANRAG_SCAN(true, false); else ANRAG_SCAN(false, false);
+struct ScanShape {
+    static constexpr int kG = G, kCH = CH, kR = scan_r<CH>();
+};
+
+// dim -> kernel shape; calls f(ScanShape<G, CH>{}) and returns true, or false for a dimension only the generic kernel takes
+template <class F>
+static bool scan_dispatch(int d, F &&f) {
+    if (d % 256 == 0 && d / 256 <= 16) {
+        switch (d / 256) {
+            case 1: f(ScanShape<32, 2>{}); return true;  // 256-d: two rows per load (<64,1>: 65 % of HBM peak, this: 86 %)
+            case 2: f(ScanShape<64, 2>{}); return true;
+            case 3: f(ScanShape<64, 3>{}); return true;
+            case 4: f(ScanShape<64, 4>{}); return true;
+            case 6: f(ScanShape<64, 6>{}); return true;
+            case 8: f(ScanShape<64, 8>{}); return true;
+            case 12: f(ScanShape<64, 12>{}); return true;  // 3072
+            case 16: f(ScanShape<64, 16>{}); return true;  // 4096
+            default: return false;
+        }
     }
-#undef ANRAG_SCAN_R
-#undef ANRAG_SCAN
+    if (d % 128 == 0 && d / 128 <= 8) {
+        switch (d / 128) {
+            case 1: f(ScanShape<32, 1>{}); return true;
+            case 3: f(ScanShape<32, 3>{}); return true;
+            case 5: f(ScanShape<32, 5>{}); return true;
+            case 7: f(ScanShape<32, 7>{}); return true;
+            default: return false;
+        }
+    }
+    if (d % 64 == 0 && d / 64 <= 8) {
+        switch (d / 64) {
+            case 1: f(ScanShape<16, 1>{}); return true;
+            case 3: f(ScanShape<16, 3>{}); return true;
+            case 5: f(ScanShape<16, 5>{}); return true;
+            case 7: f(ScanShape<16, 7>{}); return true;
+            default: return false;
+        }
+    }
+    return false;
+}
+
+// VGPRs of the scan kernel this index's queries run (the filtered top-k variant: the larger one).  K3 sizes its
+// workgroups so that they fit NEXT TO a scan wave on every SIMD (bm25.hip).
+int dense_scan_vgprs(const anrag_index *idx) {
+    int regs = 128;
+    const bool known = scan_dispatch(idx->dim, [&](auto shape) {
+        using S = decltype(shape);
+        hipFuncAttributes attr;
+        if (hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(
+                                            &dense_scan_kernel<S::kG, S::kCH, S::kR, true, false>)) == hipSuccess)
+            regs = attr.numRegs;
+    });
+    if (!known) {
+        hipFuncAttributes attr;
+        if (hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(&dense_scan_topk_generic_kernel)) == hipSuccess)
+            regs = attr.numRegs;
+    }
+    return regs;
 }
 
 int launch_dense_scan(anrag_index *idx, hipStream_t st, const float *d_query, int32_t k,
@@ -351,39 +461,18 @@ int launch_dense_scan_group(anrag_index *idx, hipStream_t st, const float *const
     const uint32_t *allow = (idx->d_dense_src != nullptr) ? d_allow_bits : nullptr;
     {
         LaunchTimer t(idx, ANRAG_KERNEL_DENSE_SCAN, st, n_queries);
-        bool done = true;
-        if (d % 256 == 0 && d / 256 <= 16) {
-            switch (d / 256) {
-                case 1: launch_scan<32, 2>(grid, st, idx, Q, k, allow, d_scores_out); break;  // 256-d: two rows per
-                                                                                                         // load (<64,1>: 65 % of HBM peak, this: 86 %)
-                case 2: launch_scan<64, 2>(grid, st, idx, Q, k, allow, d_scores_out); break;
-                case 3: launch_scan<64, 3>(grid, st, idx, Q, k, allow, d_scores_out); break;
-                case 4: launch_scan<64, 4>(grid, st, idx, Q, k, allow, d_scores_out); break;
-                case 6: launch_scan<64, 6>(grid, st, idx, Q, k, allow, d_scores_out); break;
-                case 8: launch_scan<64, 8>(grid, st, idx, Q, k, allow, d_scores_out); break;
-                case 12: launch_scan<64, 12>(grid, st, idx, Q, k, allow, d_scores_out); break;  // 3072
-                case 16: launch_scan<64, 16>(grid, st, idx, Q, k, allow, d_scores_out); break;  // 4096
-                default: done = false;
+        const bool done = scan_dispatch(d, [&](auto shape) {
+            using S = decltype(shape);
+#define ANRAG_SCAN(F, SC)                                                                                  \
+    dense_scan_kernel<S::kG, S::kCH, S::kR, F, SC><<<grid, kScanThreads, 0, st>>>(                            \
+        idx->d_emb, Q, idx->n_rows, idx->dim, k, idx->d_dense_src, allow, d_scores_out)
+            if (d_scores_out) {
+                if (allow) ANRAG_SCAN(true, true); else ANRAG_SCAN(false, true);
+            } else {
+                if (allow) ANRAG_SCAN(true, false); else ANRAG_SCAN(false, false);
             }
-        } else if (d % 128 == 0 && d / 128 <= 8) {
-            switch (d / 128) {
-                case 1: launch_scan<32, 1>(grid, st, idx, Q, k, allow, d_scores_out); break;
-                case 3: launch_scan<32, 3>(grid, st, idx, Q, k, allow, d_scores_out); break;
-                case 5: launch_scan<32, 5>(grid, st, idx, Q, k, allow, d_scores_out); break;
-                case 7: launch_scan<32, 7>(grid, st, idx, Q, k, allow, d_scores_out); break;
-                default: done = false;
-            }
-        } else if (d % 64 == 0 && d / 64 <= 8) {
-            switch (d / 64) {
-                case 1: launch_scan<16, 1>(grid, st, idx, Q, k, allow, d_scores_out); break;
-                case 3: launch_scan<16, 3>(grid, st, idx, Q, k, allow, d_scores_out); break;
-                case 5: launch_scan<16, 5>(grid, st, idx, Q, k, allow, d_scores_out); break;
-                case 7: launch_scan<16, 7>(grid, st, idx, Q, k, allow, d_scores_out); break;
-                default: done = false;
-            }
-        } else {
-            done = false;
-        }
+#undef ANRAG_SCAN
+        });
         if (!done) {  // odd dimensions: one launch per query
             (void)d_query; (void)blk_s; (void)blk_r;
             for (int i = 0; i < n_queries; ++i)
