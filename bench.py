@@ -618,7 +618,14 @@ def also_measurements(args, torch, nat, lib, idx, Index, synth, E, Q, T, n_terms
             idx.profile(False)
             r = batched_roofline(256, n_rows, dim, ms / max(n, 1), n, mode == "bf16x3")
             r["queries_per_s"] = 256.0 / (ms / max(n, 1) * 1e-3)
-            r["ids_match_k1_on_4_queries"] = bool(torch.equal(outb[:4, :, 1], ref[:, :, 1])) and int(flag[:4].abs().sum()) == 0
+            # K2's answers for 4 of the queries against K1's: rank by rank within the 1e-4 bar (ids may swap inside a
+            # near-tie under the split-precision arithmetic, whose scores sit ~1e-6 from the f32 ones)
+            got_s = outb[:4, :, 0].cpu().numpy().view(np.float64)
+            ref_s = ref[:, :, 0].cpu().numpy().view(np.float64)
+            r["vs_k1_on_4_queries"] = {"ids_equal": bool(torch.equal(outb[:4, :, 1], ref[:, :, 1])),
+                                       "max_abs_score_diff": float(np.max(np.abs(got_s - ref_s))),
+                                       "within_1e-4": bool(np.max(np.abs(got_s - ref_s)) <= 1e-4),
+                                       "overflow_flags": int(flag[:4].abs().sum())}
             res["c4_256x%dx%d_%s" % (n_rows, dim, mode)] = r
         idx.set_batched_precision("f32")
     # ---- K3 and the tail alone (they hide under K1 in the hybrid pipeline)
