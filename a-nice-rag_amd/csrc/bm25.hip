@@ -271,7 +271,12 @@ __global__ __launch_bounds__(THREADS, THREADS == kBm25Threads ? 5 : 1) void bm25
 #pragma unroll
                 for (int u = 0; u < kRoundSlots / 2; ++u) {
                     const int64_t d = g_doc[h + u];
-                    if (d >= lo && d < hi) slice[d - lo] = slice[d - lo] + g_w[u] * g_val[h + u];
+                    // ds_add_f64: one LDS instruction instead of read -> wait -> add -> write (the slice is touched
+                    // once per document and term, so this is the same IEEE addition, without the read's latency in
+                    // front of every term's barrier; scores stay bit-identical: tests/test_gpu_bm25.py)
+                    if (d >= lo && d < hi)
+                        __builtin_amdgcn_ds_atomic_fadd_f64(
+                            (__attribute__((address_space(3))) double *)(slice + (d - lo)), g_w[u] * g_val[h + u]);
                     if ((last_of_term >> (h + u)) & 1u) __syncthreads();  // term complete before the next touches the same document
                 }
             }
