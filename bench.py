@@ -333,9 +333,10 @@ def run_rank(args) -> int:
     finish()
     # HIP events around the dominant kernel only, on a SAMPLE of its launches, on the stream it is launched on: a
     # bracket holds its stream for ~10 us, which at batch=1 would be charged to every query (measured: 463 -> 452
-    # us/step at 1M rows).  A sharded K1 launch carries a whole exchange group: every 2nd launch.
+    # us/step at 1M rows; a sharded K1 launch carries a whole exchange group and paid 10 us per 2 launches = 2 % at the
+    # 125k-row shard): every 8th launch here, every launch in the separate pass below.
     main_kernel = nat.KERNEL_DENSE_BATCHED if batched else nat.KERNEL_DENSE_SCAN
-    idx.profile(True, kernels=[main_kernel], every=1 if batched else (2 if sharded else 8))
+    idx.profile(True, kernels=[main_kernel], every=1 if batched else 8)
     idx.profile_reset()
     barrier()
     t0 = time.perf_counter()
@@ -346,7 +347,7 @@ def run_rank(args) -> int:
     elapsed = time.perf_counter() - t0
     scan_ms, scan_n = idx.profile_read(main_kernel)
     scan_units = idx.profile_units(main_kernel)  # queries the timed launches carried (sharded: a group per K1 launch)
-    sampled = "every %s launch of the timed region" % ("" if batched else ("2nd" if sharded else "8th"))
+    sampled = "every %s launch of the timed region" % ("" if batched else "8th")
     if world > 1:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
