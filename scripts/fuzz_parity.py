@@ -26,7 +26,7 @@ def run(budget: float = 60.0, seed: int = 0) -> int:
     rng = np.random.default_rng(seed)
     t_end = time.time() + budget
     rounds = checks = 0
-    DIMS = [8, 24, 64, 128, 192, 256, 320, 384, 448, 512, 640, 768, 896, 1024, 1536, 2048]
+    DIMS = [8, 24, 64, 128, 192, 256, 320, 384, 448, 512, 640, 768, 896, 1024, 1536, 2048, 3072, 4096]
     while time.time() < t_end:
         rounds += 1
         n = int(rng.choice([1, 2, 3, 17, 63, 64, 65, 255, 257, 1000, 4095, 4096, 4097, 9000, 20000]))
@@ -111,5 +111,62 @@ def run(budget: float = 60.0, seed: int = 0) -> int:
     return checks
 
 
+def run_big(budget: float = 60.0, seed: int = 0) -> int:
+    """BM25 on corpora of 262k .. 1.2M documents (partitions of 1,280 .. 4,096 documents: the 1,024-thread form of
+    K3, which the corpora of run() never reach), built on the GPU (anrag.synth), against the oracle's CSR scorer:
+    score vectors and top-k bit for bit; random vocabulary sizes and document lengths (all-zero partitions, heavy
+    ties, terms that are in every document), term lists with duplicates / unknown ids / up to 40 terms, filters."""
+    import torch
+    from oracle import ref_bm25
+    from anrag import synth
+
+    rng = np.random.default_rng(seed)
+    dev = torch.device("cuda", 0)
+    t_end = time.time() + budget
+    rounds = checks = 0
+    while time.time() < t_end:
+        rounds += 1
+        n = int(rng.integers(262_145, 1_200_000))
+        vocab = int(rng.choice([40, 3000, 120_000]))
+        median_len = float(rng.choice([1.5, 12.0, 60.0]))
+        post = synth.bm25_postings(n, vocab, int(rng.integers(1 << 30)), dev, median_len=median_len)
+        idf = synth.bm25_idf(post["df"].cpu().numpy(), n)
+        if rng.random() < 0.3:
+            idf[rng.integers(0, vocab, size=max(1, vocab // 10))] = 0.0  # `idf or 0`: such terms contribute nothing
+        avgdl = post["total_len"] / n
+        n_src = int(rng.integers(1, 9))
+        sid = rng.integers(0, n_src, size=n).astype(np.uint16)
+        torch.cuda.synchronize()
+        post_doc, post_tf = post["post_doc"].cpu().numpy(), post["post_tf"].cpu().numpy()
+        df = np.diff(post["indptr"])
+        log("big corpus", rounds, "n", n, "vocab", vocab, "median_len", median_len, "postings", len(post_doc))
+        with Index(0) as idx:
+            idx.bm25_load(post["indptr"], post_doc, post_tf, idf, post["doc_len"], avgdl, 1.7, 0.83, source_id=sid)
+            for trial in range(5):
+                nt = int(rng.choice([0, 1, 2, 9, 17, 40]))
+                frequent = np.argsort(-df)[: max(1, min(vocab, 50))]
+                terms = [int(rng.choice(frequent)) if rng.random() < 0.4 else int(rng.integers(-1, vocab)) for _ in range(nt)]
+                if nt and rng.random() < 0.3:
+                    terms.append(terms[0])
+                k = int(rng.choice([1, 5, 25, 64]))
+                allow = None if rng.random() < 0.5 else (rng.random(n_src) < 0.6).astype(np.uint8)
+                mask = None if allow is None else allow[sid].astype(bool)
+                log("  trial", trial, "terms", terms, "k", k, "filter", allow is not None)
+                want = ref_bm25.csr_get_scores(post["indptr"], post_doc, post_tf, idf, post["doc_len"], avgdl, 1.7, 0.83, terms)
+                assert np.array_equal(idx.bm25_scores(terms), want), ("big bm25 score vector", n, vocab, terms)
+                doc, sc, cnt = idx.bm25_search(terms, k, allow)
+                rows = ref_search.canonical_topk(want, k, mask)
+                assert cnt == len(rows) and doc[:cnt].tolist() == rows.tolist(), ("big bm25 ids", n, vocab, k, terms)
+                assert np.array_equal(sc[:cnt], want[rows]), ("big bm25 scores", n, vocab, k, terms)
+                checks += 1
+    print(f"big-partition fuzz ok: {rounds} corpora, {checks} query checks in {budget:.0f} s (seed {seed})")
+    return checks
+
+
 if __name__ == "__main__":
-    run(float(sys.argv[1]) if len(sys.argv) > 1 else 60.0, int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    if len(sys.argv) > 3 and sys.argv[3] == "big":
+        run_big(budget, seed)
+    else:
+        run(budget, seed)

@@ -10,9 +10,18 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def test_seeded_fuzz_against_the_oracle():
+def _fuzzer():
     path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "fuzz_parity.py")
     spec = importlib.util.spec_from_file_location("fuzz_parity", path)
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    assert mod.run(budget=12.0, seed=20260) > 200
+    return mod
+
+
+def test_seeded_fuzz_against_the_oracle():
+    assert _fuzzer().run(budget=12.0, seed=20260) > 200
+
+
+def test_seeded_fuzz_of_bm25_on_large_partitions():
+    """262k .. 1.2M documents: the 1,024-thread form of K3 (partitions of 1,280 .. 4,096 documents)."""
+    assert _fuzzer().run_big(budget=15.0, seed=20261) >= 10
