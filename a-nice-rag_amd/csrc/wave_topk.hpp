@@ -248,55 +248,41 @@ template <typename S>
 __device__ __forceinline__ void merge_lists(WaveTopK<S> &top, const S *__restrict__ blk_score,
                                             const uint32_t *__restrict__ blk_row, int32_t n_lists, int32_t k,
                                             int wave_in_group, int n_waves) {
-    constexpr int kPre = 4;    // entries of a list pulled ahead
-    constexpr int kBatch = 4;  // chunks of 64 lists whose heads are pulled in ONE round of loads (K1 leaves 1,024 lists:
-                               // 4 chunks per wave; chunk after chunk was 4 dependent HBM round trips, 2-4 us each
-                               // under a running scan)
+    constexpr int kPre = 4;
     const int lane = lane_id();
-    for (int l0 = wave_in_group * kWave; l0 < n_lists; l0 += n_waves * kWave * kBatch) {
-        S es[kBatch][kPre];
-        uint32_t er[kBatch][kPre];
+    for (int l0 = wave_in_group * kWave; l0 < n_lists; l0 += n_waves * kWave) {
+        const int list = l0 + lane;
+        bool live = list < n_lists;
+        const S *ps = blk_score + (int64_t)(live ? list : 0) * kListLen;
+        const uint32_t *pr = blk_row + (int64_t)(live ? list : 0) * kListLen;
+        S es[kPre];
+        uint32_t er[kPre];
 #pragma unroll
-        for (int b = 0; b < kBatch; ++b) {
-            const int list = l0 + b * n_waves * kWave + lane;
-            const bool live = list < n_lists;
-            const S *ps = blk_score + (int64_t)(live ? list : 0) * kListLen;
-            const uint32_t *pr = blk_row + (int64_t)(live ? list : 0) * kListLen;
-#pragma unroll
-            for (int j = 0; j < kPre; ++j) {
-                es[b][j] = (live && j < k) ? ps[j] : neg_inf<S>();
-                er[b][j] = (live && j < k) ? pr[j] : kNoRow;
-            }
+        for (int j = 0; j < kPre; ++j) {
+            es[j] = (live && j < k) ? ps[j] : neg_inf<S>();
+            er[j] = (live && j < k) ? pr[j] : kNoRow;
         }
+        bool done = false;
 #pragma unroll
-        for (int b = 0; b < kBatch; ++b) {
-            const int list = l0 + b * n_waves * kWave + lane;
-            if (l0 + b * n_waves * kWave >= n_lists) break;  // wave-uniform
-            bool live = list < n_lists;
-            const S *ps = blk_score + (int64_t)(live ? list : 0) * kListLen;
-            const uint32_t *pr = blk_row + (int64_t)(live ? list : 0) * kListLen;
-            bool done = false;
-#pragma unroll
-            for (int j = 0; j < kPre; ++j) {
-                if (!done) {
-                    const bool cand = live && er[b][j] != kNoRow && top.admits(es[b][j], er[b][j]);
-                    if (__ballot(cand) == 0) {
-                        done = true;
-                    } else {
-                        top.offer_lanes(cand, es[b][j], er[b][j]);
-                        live = cand && !beats(top.thr_s, top.thr_r, es[b][j], er[b][j]);  // pushed out again: exhausted
-                    }
+        for (int j = 0; j < kPre; ++j) {
+            if (!done) {
+                const bool cand = live && er[j] != kNoRow && top.admits(es[j], er[j]);
+                if (__ballot(cand) == 0) {
+                    done = true;
+                } else {
+                    top.offer_lanes(cand, es[j], er[j]);
+                    live = cand && !beats(top.thr_s, top.thr_r, es[j], er[j]);  // pushed out again: exhausted
                 }
             }
-            if (done) continue;
-            for (int j = kPre; j < k; ++j) {  // rare: one list holds more than kPre winners
-                const S cs = live ? ps[j] : neg_inf<S>();
-                const uint32_t cr = live ? pr[j] : kNoRow;
-                const bool cand = live && cr != kNoRow && top.admits(cs, cr);
-                if (__ballot(cand) == 0) break;
-                top.offer_lanes(cand, cs, cr);
-                live = cand && !beats(top.thr_s, top.thr_r, cs, cr);
-            }
+        }
+        if (done) continue;
+        for (int j = kPre; j < k; ++j) {  // rare: one list holds more than kPre winners
+            const S cs = live ? ps[j] : neg_inf<S>();
+            const uint32_t cr = live ? pr[j] : kNoRow;
+            const bool cand = live && cr != kNoRow && top.admits(cs, cr);
+            if (__ballot(cand) == 0) break;
+            top.offer_lanes(cand, cs, cr);
+            live = cand && !beats(top.thr_s, top.thr_r, cs, cr);
         }
     }
 }
