@@ -137,6 +137,9 @@ struct anrag_index {
     int64_t bsample_cap = 0;
     bool batched_split = false;         // K2 arithmetic: false = exact f32 MFMA, true = bf16 x 3 split products
     void *d_bq_hi = nullptr, *d_bq_lo = nullptr;  // bf16 halves of the padded query block
+    void *d_split_img = nullptr;        // split-precision K2: the corpus as ready-to-copy LDS images (built on first use)
+    int64_t split_img_bytes = 0;
+    void *d_bq_img = nullptr;           // ... and the query block in the same form
     // WRRF scratch
     int64_t *d_w_ids = nullptr, *d_w_in = nullptr;
     double *d_w_contrib = nullptr, *d_w_score = nullptr;

@@ -37,7 +37,12 @@ template <int QW>
 struct BatchGeom {
     static constexpr int kThreads = QW * 2;                 // waves = 2 (row halves) x QW/64 (query columns)
     static constexpr int kBufFloats = (kBM + QW) * kLdk;
-    static constexpr int kLdsBytes = 2 * kBufFloats * 4;
+    static constexpr int kStageBytes = 2 * kBufFloats * 4;
+    // survivor slices (dense_batched_common.hpp): 4 KB per wave for the one-workgroup-per-CU shape, 1 KB per wave
+    // where two workgroups share the CU's 160 KB
+    static constexpr int kSurvSlice = QW == 256 ? 4096 : 1024;
+    static constexpr int kSurvEntries = QW == 256 ? 448 : 112;
+    static constexpr int kLdsBytes = kStageBytes + (kThreads / 64) * kSurvSlice;
     static constexpr int kStageE = kBM * 8 / kThreads;      // float4 per thread per k-step, corpus tile
     static constexpr int kStageQ = QW * 8 / kThreads;       // = 4
 };
@@ -72,8 +77,13 @@ __global__ __launch_bounds__(BatchGeom<QW>::kThreads, 2) void dense_batched_kern
     float my_tau[2] = {0.f, 0.f};
     if constexpr (!SAMPLE) {
 #pragma unroll
-        for (int tj = 0; tj < 2; ++tj) my_tau[tj] = tau[qbase + qw * 64 + tj * 32 + l31];
+        for (int tj = 0; tj < 2; ++tj) {  // padding queries (zero rows of the block) never keep a score
+            const int q = qbase + qw * 64 + tj * 32 + l31;
+            my_tau[tj] = q < nq ? tau[q] : 3.0e38f;
+        }
     }
+    int surv_fill = 0;  // wave-uniform: entries in this wave's survivor slice
+    unsigned char *slice = reinterpret_cast<unsigned char *>(lds) + Geo::kStageBytes + wave * Geo::kSurvSlice;
 
     // Staging cursor: (tile, k-step) of the NEXT load_stage call, advanced incrementally -- a 64-bit divide and
     // six 64-bit address multiplies per k-step were ~10 % of the loop before.
@@ -195,30 +205,64 @@ __global__ __launch_bounds__(BatchGeom<QW>::kThreads, 2) void dense_batched_kern
         }
         if (++cur_ks == ksteps) {
             batched_tile_epilogue<SAMPLE, FILTER>(acc, cur_tile, rw, qw, qbase, l31, lh, my_tau, n_work, stride, nq,
-                                                  sample_scores, cnt, cand, cap, src, allow_bits);
+                                                  sample_scores, cnt, cand, cap, src, allow_bits, slice,
+                                                  Geo::kSurvEntries, surv_fill);
             cur_ks = 0;
             cur_tile += tile_step;
         }
         __syncthreads();
     }
+    if constexpr (!SAMPLE) {
+        if (surv_fill) flush_survivors(slice, Geo::kSurvEntries, surv_fill, cnt, cand, cap);
+    }
 }
 
 // tau[q] = k-th best sampled score of query q (or -inf when fewer than k allowed rows were sampled)
-__global__ __launch_bounds__(64) void batched_threshold_kernel(const float *__restrict__ sample_scores, int64_t n_sample,
-                                                               int32_t k, float *__restrict__ tau,
-                                                               int32_t *__restrict__ cnt) {
-    const int q = blockIdx.x, lane = threadIdx.x;
+// One workgroup of 8 waves per query: the k-th best score of its sample row.  Each wave takes every eighth chunk of
+// 1,024 scores with sixteen independent loads per lane in flight (one wave and one load at a time, this kernel cost as
+// much as half the sampled pass), the eight lists meet through LDS.
+__global__ __launch_bounds__(kThrWaves * 64) void batched_threshold_kernel(const float *__restrict__ sample_scores,
+                                                                           int64_t n_sample, int32_t k,
+                                                                           float *__restrict__ tau,
+                                                                           int32_t *__restrict__ cnt) {
+    __shared__ float lds_s[kThrWaves * kListLen];
+    __shared__ uint32_t lds_r[kThrWaves * kListLen];
+    const int q = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     WaveTopK<float> top;
     top.init(k);
     const float *s = sample_scores + (int64_t)q * n_sample;
-    for (int64_t i0 = 0; i0 < n_sample; i0 += kWave) {
-        const int64_t i = i0 + lane;
-        const float v = i < n_sample ? s[i] : neg_inf<float>();
-        // rows are only a tie-break here; sample index stands in
-        top.offer_lanes(i < n_sample && v > neg_inf<float>() && top.admits(v, (uint32_t)i), v, (uint32_t)i);
+    constexpr int kDeep = 16;  // independent loads per lane: the scan is a chain of HBM / L2 round trips otherwise
+    for (int64_t i0 = (int64_t)wave * (kDeep * 64); i0 < n_sample; i0 += kThrWaves * kDeep * 64) {
+        float v[kDeep];
+#pragma unroll
+        for (int j = 0; j < kDeep; ++j) {
+            const int64_t i = i0 + j * 64 + lane;
+            v[j] = i < n_sample ? s[i] : neg_inf<float>();
+        }
+        // the best of each lane's sixteen first: one sorted offer lifts the threshold so far that the other fifteen
+        // rounds rarely pass admits() (offering sixteen full rounds to an empty list is sixteen sort-and-merge networks)
+        float m = v[0];
+        int jm = 0;
+#pragma unroll
+        for (int j = 1; j < kDeep; ++j)
+            if (v[j] > m) {
+                m = v[j];
+                jm = j;
+            }
+        const uint32_t im = (uint32_t)(i0 + jm * 64 + lane);  // rows are only a tie-break here: the sample index
+        top.offer_lanes(m > neg_inf<float>() && top.admits(m, im), m, im);
+#pragma unroll
+        for (int j = 0; j < kDeep; ++j) {
+            const uint32_t i = (uint32_t)(i0 + j * 64 + lane);
+            top.offer_lanes(j != jm && v[j] > neg_inf<float>() && top.admits(v[j], i), v[j], i);
+        }
     }
-    if (lane == 0) {
+    block_merge(top, lds_s, lds_r, kThrWaves);
+    if (threadIdx.x == 0) {
         tau[q] = top.thr_r == kNoRow ? neg_inf<float>() : top.thr_s;
+#if defined(K2_EXP) && K2_EXP == 3
+        tau[q] = 3e38f;  // experiment: no survivors at all
+#endif
         cnt[q] = 0;
     }
 }
@@ -263,6 +307,7 @@ static int ensure_batched_workspace(anrag_index *idx, int64_t n_sample) {
         ANRAG_HIP(hipMalloc(reinterpret_cast<void **>(&idx->d_bq), (size_t)kBQ * idx->dim * sizeof(float)));
         ANRAG_HIP(hipMalloc(reinterpret_cast<void **>(&idx->d_btau), kBQ * sizeof(float)));
         ANRAG_HIP(hipMalloc(reinterpret_cast<void **>(&idx->d_bcnt), kBQ * sizeof(int32_t)));
+        ANRAG_HIP(hipMemset(idx->d_bcnt, 0, kBQ * sizeof(int32_t)));  // the counters of padding queries are never reset
         ANRAG_HIP(hipMalloc(reinterpret_cast<void **>(&idx->d_bflag), kBQ * sizeof(int32_t)));
         ANRAG_HIP(hipMalloc(reinterpret_cast<void **>(&idx->d_bcand), (size_t)kBQ * kCandCap * sizeof(Cand32)));
         idx->hbm_bytes += (int64_t)kBQ * idx->dim * 4 + (int64_t)kBQ * kCandCap * 8;
@@ -279,12 +324,14 @@ static int ensure_batched_workspace(anrag_index *idx, int64_t n_sample) {
 
 void free_batched(anrag_index *idx) {
     void *ptrs[] = {idx->d_bq,    idx->d_btau,    idx->d_bcnt,  idx->d_bflag,
-                    idx->d_bcand, idx->d_bsample, idx->d_bq_hi, idx->d_bq_lo};
+                    idx->d_bcand, idx->d_bsample, idx->d_bq_hi, idx->d_bq_lo, idx->d_split_img, idx->d_bq_img};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     idx->d_bq = idx->d_btau = idx->d_bsample = nullptr;
     idx->d_bcnt = idx->d_bflag = nullptr;
-    idx->d_bcand = idx->d_bq_hi = idx->d_bq_lo = nullptr;
+    idx->d_bcand = idx->d_bq_hi = idx->d_bq_lo = idx->d_split_img = idx->d_bq_img = nullptr;
+    idx->hbm_bytes -= idx->split_img_bytes;
+    idx->split_img_bytes = 0;
     idx->bsample_cap = 0;
 }
 
@@ -338,7 +385,7 @@ static int batched_passes(anrag_index *idx, hipStream_t st, int32_t nq, int32_t 
         dense_batched_kernel<128, true, false><<<batched_grid<128>(idx, n_sample, sq), GeoS::kThreads, GeoS::kLdsBytes, st>>>(
             idx->d_emb, idx->d_bq, sq, n, dim, nq, n_sample, stride, nullptr, idx->d_bsample, nullptr, nullptr, 0,
             nullptr, nullptr);
-    batched_threshold_kernel<<<nq, 64, 0, st>>>(idx->d_bsample, n_sample, k, idx->d_btau, idx->d_bcnt);
+    batched_threshold_kernel<<<nq, kThrWaves * 64, 0, st>>>(idx->d_bsample, n_sample, k, idx->d_btau, idx->d_bcnt);
     if (allow)
         dense_batched_kernel<QW, false, true><<<batched_grid<QW>(idx, n, n_qblocks), Geo::kThreads, Geo::kLdsBytes, st>>>(
             idx->d_emb, idx->d_bq, n_qblocks, n, dim, nq, n, 1, idx->d_btau, nullptr, idx->d_bcnt, cand, kCandCap,
@@ -358,10 +405,24 @@ int launch_dense_batched(anrag_index *idx, hipStream_t st, const float *d_querie
     const int64_t n = idx->n_rows;
     const int dim = idx->dim;
     const uint32_t *allow = idx->d_dense_src ? d_allow_bits : nullptr;
-    // sample size: expected survivors per query = N*k/S = cap/4
-    int64_t n_sample = (4 * n * (int64_t)k + kCandCap - 1) / kCandCap;
+    // Sample size.  A score survives the full pass when it reaches the k-th best of the S sampled rows: N*k/S expected
+    // survivors per query.  The sampled pass costs ~1 ns per row (beyond the ~64k rows that merely fill the CUs), a
+    // survivor ~0.8 ns x 256 queries: the sum is smallest near S = sqrt(128 N k) (36k rows, ~280 survivors per query at
+    // 1M x k=10; a fixed N*k/S = cap/4 = 2,048 made the survivors 6 % of the f32 pass and 30 % of the split one).  The
+    // f32 pass costs ~3 ns per row and its survivors ~0.4 ns: sqrt(32 N k).
+    // Never fewer rows than keep the expected survivors under cap/4.
+    int64_t n_sample = (int64_t)__builtin_sqrt((idx->batched_split ? 128.0 : 32.0) * (double)n * (double)k);
+    const int64_t floor_rows = (4 * n * (int64_t)k + kCandCap - 1) / kCandCap;
+    if (n_sample < floor_rows) n_sample = floor_rows;
     if (n_sample < 4096) n_sample = 4096;
     if (n_sample > n) n_sample = n;
+    // a round of tiles (one per CU) costs the same whether the tiles are all there or not: fill the round, as long as the
+    // sample stays a small part of the corpus
+    const int64_t round_rows = (int64_t)idx->n_cus * (idx->batched_split ? 256 : kBM);
+    const int64_t filled = (n_sample + round_rows - 1) / round_rows * round_rows;
+    if (filled <= n / 8) n_sample = filled;
+    n_sample &= ~(int64_t)3;  // the sampled pass stores four scores at a time
+    if (n_sample < 4) n_sample = n;
     const int64_t stride = n / n_sample;
     int rc = ensure_batched_workspace(idx, n_sample);
     if (rc) return rc;

@@ -12,57 +12,129 @@ constexpr int kBM = 128;  // corpus rows per workgroup tile
 constexpr int kBQ = 256;  // queries per pass
 constexpr int kBK = 32;   // k per staging step
 constexpr int32_t kCandCap = 8192;
+constexpr int kThrWaves = 8;  // batched_threshold_kernel: waves per query
 
 struct Cand32 {
     float score;
     uint32_t row;
 };
 
+// Survivors of the full pass (score >= the query's threshold) are rare -- a few per wave and tile -- so a wave parks
+// them in its own slice of LDS (no atomics: the wave is the only writer, positions come from a ballot) and sends them
+// to the per-query candidate lists in HBM in one go, when the slice fills up and at the end of the kernel: the global
+// atomics of a whole slice are in flight together instead of one round trip per score in the middle of the tile loop
+// (which cost 6 % of the f32 pass and 30 % of the split-precision one).  A slice of `entries` survivors takes
+// entries * 9 bytes: scores, rows, query numbers (< 256).
+struct SurvBuf {
+    float *score;
+    uint32_t *row;
+    uint8_t *q;
+};
+__device__ __forceinline__ SurvBuf surv_buf(unsigned char *slice, int entries) {
+    return {reinterpret_cast<float *>(slice), reinterpret_cast<uint32_t *>(slice + entries * 4), slice + entries * 8};
+}
+
+static __device__ __noinline__ void flush_survivors(unsigned char *slice, int entries, int n, int32_t *__restrict__ cnt,
+                                                    Cand32 *__restrict__ cand, int32_t cap) {
+    const SurvBuf b = surv_buf(slice, entries);
+    for (int i = lane_id(); i < n; i += kWave) {
+        const int q = b.q[i];
+        const int pos = atomicAdd(&cnt[q], 1);
+        if ((uint32_t)pos < (uint32_t)cap) {
+            Cand32 c;
+            c.score = b.score[i];
+            c.row = b.row[i];
+            cand[(int64_t)q * cap + pos] = c;
+        }
+    }
+    // atomics and stores count in vmcnt like the LDS-DMA copies of the split-precision kernel: drain them, so that its
+    // counted waits keep meaning "my copies of the stage two back have landed"
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+}
+
+// The per-score path for one 32 x 32 accumulator tile that holds at least one survivor (lane = query column q with
+// threshold tau_q -- +huge for a padding query; register r = row row0 + (r&3) + 8*(r>>2), row0 includes 4 * lane half).
+// Returns the wave's new fill.
+template <bool FILTER>
+__device__ __noinline__ int tile_survivors(f32x16 v, int64_t row0, int q, int32_t nq, float tau_q, int64_t n_work,
+                                           unsigned char *slice, int entries, int fill, int32_t *__restrict__ cnt,
+                                           Cand32 *__restrict__ cand, int32_t cap, const uint16_t *__restrict__ src,
+                                           const uint32_t *__restrict__ allow_bits) {
+    const SurvBuf b = surv_buf(slice, entries);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        float s = v[r];
+        if (__builtin_amdgcn_ballot_w64(!(s < tau_q)) == 0) continue;  // !(s < tau): survivors and NaNs
+        const int64_t wr = row0 + (r & 3) + 8 * (r >> 2);
+        // q < nq: a NaN / inf row scores NaN against the zero rows of the query block too
+        bool ok = !(s < tau_q) && wr < n_work && q < nq;
+        if constexpr (FILTER) {
+            if (ok) ok = source_ok(allow_bits, src[wr]);
+        }
+        if (s != s) s = __builtin_huge_valf();  // NaN ranks first, as in K1 (and in numpy)
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(ok);
+        if (ok) {
+            const int at = fill + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
+            b.score[at] = s;
+            b.row[at] = (uint32_t)wr;
+            b.q[at] = (uint8_t)q;
+        }
+        fill += __builtin_popcountll(m);
+        if (fill > entries - kWave) {
+            flush_survivors(slice, entries, fill, cnt, cand, cap);
+            fill = 0;
+        }
+    }
+    return fill;
+}
+
 // Epilogue of one (64*TI) x QW tile held as TI x 2 MFMA accumulators per wave: D[corpus row][query], lane = query
 // column, 16 rows per register set (32x32 C/D map: row = (r&3) + 8*(r>>2) + 4*(lane>>5)).  SAMPLE: store every
-// score of the sampled rows; otherwise append survivors (score >= this query's threshold) to its candidate list.
-// Zeroes the accumulators.
+// score of the sampled rows; otherwise 16 compares per accumulator tile, and the per-score path above only for a tile
+// that holds a survivor (my_tau must be +huge for padding queries).  Zeroes the accumulators.
 template <bool SAMPLE, bool FILTER, int TI = 2>
 __device__ __forceinline__ void batched_tile_epilogue(f32x16 (&acc)[TI][2], int64_t tile, int rw, int qw, int qbase,
                                                       int l31, int lh, const float (&my_tau)[2], int64_t n_work,
                                                       int64_t stride, int32_t nq, float *__restrict__ sample_scores,
                                                       int32_t *__restrict__ cnt, Cand32 *__restrict__ cand, int32_t cap,
                                                       const uint16_t *__restrict__ src,
-                                                      const uint32_t *__restrict__ allow_bits) {
+                                                      const uint32_t *__restrict__ allow_bits, unsigned char *slice,
+                                                      int entries, int &fill) {
     // a workgroup tile is 2 (row halves) x TI x 32 corpus rows: TI = 2 -> 128 rows (kBM), TI = 4 -> 256 rows
 #pragma unroll
     for (int ti = 0; ti < TI; ++ti)
 #pragma unroll
         for (int tj = 0; tj < 2; ++tj) {
             const int q = qbase + qw * 64 + tj * 32 + l31;
+            const int64_t row0 = tile * (2 * TI * 32) + rw * (TI * 32) + ti * 32 + 4 * lh;
+            if constexpr (SAMPLE) {
+                // registers 4g .. 4g+3 are four consecutive rows: one 16-byte store each (n_work is a multiple of 4, so
+                // a group is inside or outside as a whole)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int64_t wr = tile * (2 * TI * 32) + rw * (TI * 32) + ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                float s = acc[ti][tj][r];
-                if (s != s) s = __builtin_huge_valf();  // NaN ranks first, as in K1 (and in numpy)
-                if constexpr (SAMPLE) {
-                    if (wr < n_work) {
-                        bool ok = true;
-                        if constexpr (FILTER) ok = source_ok(allow_bits, src[wr * stride]);
-                        sample_scores[(int64_t)q * n_work + wr] = ok ? s : neg_inf<float>();
-                    }
-                } else {
-                    if (s >= my_tau[tj] && wr < n_work && q < nq) {
-                        bool ok = true;
-                        if constexpr (FILTER) ok = source_ok(allow_bits, src[wr]);
-                        if (ok) {
-                            const int pos = atomicAdd(&cnt[q], 1);
-                            if (pos < cap) {
-                                Cand32 c;
-                                c.score = s;
-                                c.row = (uint32_t)wr;
-                                cand[(int64_t)q * cap + pos] = c;
-                            }
+                for (int g = 0; g < 4; ++g) {
+                    const int64_t wr = row0 + 8 * g;
+                    f32x4 o;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float s = acc[ti][tj][4 * g + j];
+                        if (s != s) s = __builtin_huge_valf();  // NaN ranks first, as in K1 (and in numpy)
+                        if constexpr (FILTER) {
+                            if (wr < n_work && !source_ok(allow_bits, src[(wr + j) * stride])) s = neg_inf<float>();
                         }
+                        o[j] = s;
                     }
+                    if (wr < n_work) *reinterpret_cast<f32x4 *>(sample_scores + (int64_t)q * n_work + wr) = o;
                 }
-                acc[ti][tj][r] = 0.f;
+            } else {
+                bool hit = false;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) hit |= !(acc[ti][tj][r] < my_tau[tj]);
+                if (__builtin_amdgcn_ballot_w64(hit) != 0)
+                    fill = tile_survivors<FILTER>(acc[ti][tj], row0, q, nq, my_tau[tj], n_work, slice, entries, fill, cnt,
+                                                  cand, cap, src, allow_bits);
             }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[ti][tj][r] = 0.f;
         }
 }
 

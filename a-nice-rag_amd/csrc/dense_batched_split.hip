@@ -8,12 +8,17 @@
 // The dropped lo.lo term and the rounding of lo are each <= 2^-16 |a_i||b_i| per product, so for the unit-norm
 // rows and queries of this path |error| <= ~3e-5 * sum|a_i b_i| <= 3e-5 (Cauchy-Schwarz) -- inside the 1e-4 bar
 // BASELINE.json sets for the dense side (measured: < 1e-6), but NOT the bit-level f32 result: that is why it is
-// opt-in and the default stays the exact f32 MFMA kernel.  The corpus stays fp32 in HBM (K1 needs it); each
-// tile is split while it is staged to LDS, the 256 queries are split once per pass.
+// opt-in and the default stays the exact f32 MFMA kernel.
 //
-// Tiling: 8 waves, workgroup tile 256 corpus rows x 256 queries, wave w -> rows (w&1)*128.., queries (w>>1)*64..:
-// 4 x 2 accumulator tiles of 32 x 32, 48 MFMAs per wave and k-step of 32 (a first version with 128-row tiles
-// and 24 MFMAs between barriers spent 44 % of its wave-cycles waiting: profiles/).  LDS images are bf16
+// Two kernels.  The SAMPLED pass (a few per cent of the rows, strided) reads the fp32 corpus and splits each tile
+// while it is staged to LDS -- dense_batched_split_kernel, first below.  The FULL pass streams the corpus from a
+// second copy kept as ready-to-copy bf16 hi / lo images (+4 bytes per element of HBM, built on the first
+// split-precision pass after a load) with LDS-DMA and ping-pong waves -- dense_batched_split_dma_kernel, further
+// down, with its own notes.  Both accumulate every score in the same order (per 16-wide k-step: lo.hi, hi.lo, hi.hi),
+// so a sampled row scores bit-identically in both passes and the sampled threshold is an exact lower bound.
+//
+// Sampled-pass tiling: 8 waves, workgroup tile 256 corpus rows x 256 queries, wave w -> rows (w&1)*128.., queries
+// (w>>1)*64..: 4 x 2 accumulator tiles of 32 x 32, 48 MFMAs per wave and k-step of 32.  LDS images are bf16
 // [row][32 k] = 64-byte rows whose four 16-byte chunks are XOR-swizzled with (row >> 2) & 3, which makes the
 // ds_read_b128 of one 8-element fragment per lane (lane l -> row l&31, k = 8*(l>>5) .. +8) conflict-free
 // without padding; four images per buffer (corpus hi / lo, query hi / lo), double buffered: 128 KB.
@@ -196,13 +201,217 @@ __global__ __launch_bounds__(kSplitThreads, 2) void dense_batched_split_kernel(
                 }
         }
         if (++cur_ks == ksteps) {
+            int no_fill = 0;
             batched_tile_epilogue<SAMPLE, FILTER, 4>(acc, cur_tile, rw, qw, 0, l31, lh, my_tau, n_work, stride, nq,
-                                                     sample_scores, cnt, cand, cap, src, allow_bits);
+                                                     sample_scores, cnt, cand, cap, src, allow_bits, nullptr, 0, no_fill);
             cur_ks = 0;
             cur_tile += tile_step;
         }
         __syncthreads();
     }
+}
+
+// ------------------------------------------------------------------ the full pass: LDS-DMA staging, ping-pong waves
+// The full pass streams the whole corpus once, so it gets its own kernel (the sampled pass above reads 1/16 of the
+// rows, strided, and stays on the register-staged kernel).  What is different:
+//
+//  * The corpus is kept a second time as READY-TO-COPY IMAGES (built on the first split-precision pass after a load,
+//    +4 bytes per element of HBM): for every tile of 256 rows and every k-step of 16, an 8 KB hi image and an 8 KB lo
+//    image in exactly the (swizzled) byte order the fragment reads want.  A stage is then 16 KB of corpus + 16 KB of
+//    query images copied HBM/L2 -> LDS by global_load_lds (LDS-DMA): no staging registers, no VALU split, no ds_write.
+//  * Four 32 KB stages in LDS, three in flight.
+//  * PING-PONG: waves 0-3 (one per SIMD) and waves 4-7 run half a step apart -- while one set issues its 24 MFMAs
+//    the other reads its fragments for the next step (and pushes its share of the copies), then they swap at a
+//    barrier.  The matrix pipe always has one wave feeding it and no wave needs a second fragment set (128
+//    accumulator + 48 fragment registers).  scripts/exp/k2dma_bench.hip holds the stand-alone measurements: without
+//    copies this loop is within 4 % of an MFMA-only loop; with them the kernel sits on the board's POWER limit (the
+//    shader clock falls to ~1.65 GHz: every schedule variant lands on the same 0.92 ms per 1M x 768 pass).
+//  * The tile epilogue looks at 16 scores with 16 compares and takes the per-score path only for an accumulator
+//    tile that holds a survivor (or a NaN); survivors go through a per-wave LDS buffer (below).
+constexpr int kDK = 16;                         // k per stage
+constexpr int kDImg = kSM * kDK * 2;            // one image: 256 rows x 16 bf16 = 8 KB
+constexpr int kDStage = 4 * kDImg;              // corpus hi, corpus lo, query hi, query lo
+constexpr int kDSlots = 4;
+constexpr int kDmaLdsBytes = kDSlots * kDStage;  // 128 KB
+
+// byte offset of 16-byte half `h` (k 0..7 / 8..15) of image row `row`: the two halves swap every 8 rows, so that the
+// 64 lanes of a ds_read_b128 (lane l -> row l & 31, half l >> 5) cover all banks
+__device__ __forceinline__ int dswz(int row, int h) { return row * 32 + ((h ^ ((row >> 3) & 1)) << 4); }
+
+// one thread per (row of a tile, 8-element chunk): 32 bytes of f32 in, 16 bytes into the hi and the lo image
+__global__ void split_images_kernel(const float *__restrict__ x, int64_t n_rows, int32_t dim,
+                                    unsigned char *__restrict__ img) {
+    const int chunks = dim / 8;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t row = i / chunks;
+    const int c = (int)(i - row * chunks);
+    const int64_t n_tiles = (n_rows + kSM - 1) / kSM;
+    if (row >= n_tiles * kSM) return;
+    bf16x8 h, l;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float v = row < n_rows ? x[row * dim + c * 8 + j] : 0.f;
+        const __bf16 hv = (__bf16)v;
+        h[j] = hv;
+        l[j] = (__bf16)(v - (float)hv);
+    }
+    const int64_t tile = row / kSM;
+    const int r = (int)(row - tile * kSM);
+    unsigned char *blk = img + (tile * (dim / kDK) + (c >> 1)) * (int64_t)(2 * kDImg);
+    *reinterpret_cast<bf16x8 *>(blk + dswz(r, c & 1)) = h;
+    *reinterpret_cast<bf16x8 *>(blk + kDImg + dswz(r, c & 1)) = l;
+}
+
+constexpr int kSurvEntries = 448;               // survivors per wave slice: 448 x 9 bytes = 4,032
+constexpr int kSurvSlice = 4096;
+constexpr int kDmaLdsTotal = kDmaLdsBytes + 8 * kSurvSlice;  // 160 KB: all of a CU's LDS
+
+template <bool FILTER>
+__global__ __launch_bounds__(kSplitThreads, 2) void dense_batched_split_dma_kernel(
+    const unsigned char *__restrict__ e_img, const unsigned char *__restrict__ q_img, int32_t ksteps, int32_t nq,
+    int64_t n_work, const float *__restrict__ tau, int32_t *__restrict__ cnt, Cand32 *__restrict__ cand, int32_t cap,
+    const uint16_t *__restrict__ src, const uint32_t *__restrict__ allow_bits) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int rw = wave & 1, qw = wave >> 1;
+    const int64_t n_tiles = (n_work + kSM - 1) / kSM;
+    const int64_t first_tile = blockIdx.x, tile_step = gridDim.x;
+    const int64_t my_tiles = first_tile < n_tiles ? (n_tiles - first_tile + tile_step - 1) / tile_step : 0;
+    const int64_t total = my_tiles * ksteps;
+    if (total == 0) return;
+
+    float my_tau[2];  // padding queries (zero rows of the block) never keep a score
+#pragma unroll
+    for (int tj = 0; tj < 2; ++tj) {
+        const int q = qw * 64 + tj * 32 + l31;
+        my_tau[tj] = q < nq ? tau[q] : 3.0e38f;
+    }
+    int surv_fill = 0;  // wave-uniform: entries in this wave's survivor slice
+    unsigned char *slice = lds + kDmaLdsBytes + wave * kSurvSlice;
+
+    // copies: waves 0-3 bring the 16 KB of corpus images of a stage (4 KB = four 1 KB instructions each), waves 4-7
+    // the 16 KB of query images (the same 48 x 16 KB for every tile: they come from L2).  Past the last stage the
+    // cursor stays on the last tile: the copies land in a slot nobody reads, and a branch around them would break the
+    // counted vmcnt waits.
+    int64_t ld_tile = first_tile;
+    int ld_ks = 0;
+    auto issue_stage = [&](int slot) {
+        const unsigned char *g = wave < 4 ? e_img + (ld_tile * ksteps + ld_ks) * (int64_t)(2 * kDImg) + wave * 4096
+                                          : q_img + (int64_t)ld_ks * (2 * kDImg) + (wave - 4) * 4096;
+        unsigned char *d = lds + slot * kDStage + (wave < 4 ? wave * 4096 : 2 * kDImg + (wave - 4) * 4096);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_global_load_lds(g + i * 1024 + lane * 16,
+                                             (__attribute__((address_space(3))) void *)(d + i * 1024), 16, 0, 0);
+        if (++ld_ks == ksteps) {
+            ld_ks = 0;
+            if (ld_tile + tile_step < n_tiles) ld_tile += tile_step;
+        }
+    };
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[ti][tj][r] = 0.f;
+
+    struct Frags {
+        bf16x8 ah[4], al[4], bh[2], bl[2];
+    };
+    auto read_frags = [&](int slot, Frags &f) {
+        const unsigned char *base = lds + slot * kDStage;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int off = dswz(rw * 128 + t * 32 + l31, lh);
+            f.ah[t] = *reinterpret_cast<const bf16x8 *>(base + off);
+            f.al[t] = *reinterpret_cast<const bf16x8 *>(base + kDImg + off);
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int off = dswz(qw * 64 + t * 32 + l31, lh);
+            f.bh[t] = *reinterpret_cast<const bf16x8 *>(base + 2 * kDImg + off);
+            f.bl[t] = *reinterpret_cast<const bf16x8 *>(base + 3 * kDImg + off);
+        }
+    };
+    // kind-major: the three products of one accumulator are eight MFMAs apart; small cross terms first
+    auto mfmas = [&](const Frags &f) {
+#pragma unroll
+        for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+            for (int tj = 0; tj < 2; ++tj)
+                acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.al[ti], f.bh[tj], acc[ti][tj], 0, 0, 0);
+#pragma unroll
+        for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+            for (int tj = 0; tj < 2; ++tj)
+                acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[ti], f.bl[tj], acc[ti][tj], 0, 0, 0);
+#pragma unroll
+        for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+            for (int tj = 0; tj < 2; ++tj)
+                acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[ti], f.bh[tj], acc[ti][tj], 0, 0, 0);
+    };
+    int64_t cur_tile = first_tile;
+    int cur_ks = 0;
+    auto step_done = [&]() {
+        if (++cur_ks < ksteps) return;
+        cur_ks = 0;
+        batched_tile_epilogue<false, FILTER, 4>(acc, cur_tile, rw, qw, 0, l31, lh, my_tau, n_work, 1, nq, nullptr, cnt, cand,
+                                                cap, src, allow_bits, slice, kSurvEntries, surv_fill);
+        cur_tile += tile_step;
+    };
+
+    // The compiler moves MFMAs (register-only) across an s_barrier freely: fence the scheduler around each one.
+#define ANRAG_K2_BAR()                          \
+    do {                                        \
+        __builtin_amdgcn_sched_barrier(0);      \
+        __builtin_amdgcn_s_barrier();           \
+        __builtin_amdgcn_sched_barrier(0);      \
+    } while (0)
+    issue_stage(0);
+    issue_stage(1);
+    issue_stage(2);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    ANRAG_K2_BAR();
+    // Stage c lives in slot c & 3.  Waves 0-3 read it in phase 2c and multiply in phase 2c+1; waves 4-7 read it in
+    // phase 2c+1 and multiply in phase 2c+2.  Slot (c+3) & 3 = slot of stage c-1 is free from phase 2c on (its last
+    // readers, waves 4-7, finished in phase 2c-1).  Every wave waits for its own copies of stage c+1 (vmcnt(8): two
+    // later stages may be in flight) before the barrier that ends phase 2c+1.
+    Frags f;
+    if (wave < 4) {
+        for (int64_t c = 0; c < total; ++c) {
+            __builtin_amdgcn_sched_barrier(0);
+            read_frags((int)(c & 3), f);
+            issue_stage((int)((c + 3) & 3));
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            ANRAG_K2_BAR();
+            mfmas(f);
+            step_done();
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            ANRAG_K2_BAR();
+        }
+    } else {
+        for (int64_t c = 0; c < total; ++c) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (c) {
+                mfmas(f);
+                step_done();
+            }
+            ANRAG_K2_BAR();
+            read_frags((int)(c & 3), f);
+            issue_stage((int)((c + 3) & 3));
+            asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+            ANRAG_K2_BAR();
+        }
+        mfmas(f);
+        step_done();
+    }
+#undef ANRAG_K2_BAR
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the trailing copies must not outlive the workgroup's LDS
+    if (surv_fill) flush_survivors(slice, kSurvEntries, surv_fill, cnt, cand, cap);
 }
 
 __global__ void batched_threshold_kernel(const float *, int64_t, int32_t, float *, int32_t *);  // dense_batched.hip
@@ -215,15 +424,28 @@ int batched_passes_split(anrag_index *idx, hipStream_t st, int32_t nq, int32_t k
                                       hipFuncAttributeMaxDynamicSharedMemorySize, kSplitLdsBytes));
         ANRAG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&dense_batched_split_kernel<true, true>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, kSplitLdsBytes));
-        ANRAG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&dense_batched_split_kernel<false, false>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, kSplitLdsBytes));
-        ANRAG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&dense_batched_split_kernel<false, true>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, kSplitLdsBytes));
+        ANRAG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&dense_batched_split_dma_kernel<false>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, kDmaLdsTotal));
+        ANRAG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&dense_batched_split_dma_kernel<true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, kDmaLdsTotal));
         attr_set = true;
     }
     const int64_t n = idx->n_rows;
     const int dim = idx->dim;
     const int64_t qelems = (int64_t)kBQ * dim;
+    const int64_t n_tiles = (n + kSM - 1) / kSM;
+    if (!idx->d_split_img) {  // first split-precision pass after a load: the corpus images (free_batched drops them)
+        const int64_t bytes = n_tiles * kSM * (int64_t)dim * 4;
+        ANRAG_HIP(hipMalloc(&idx->d_split_img, (size_t)bytes));
+        idx->split_img_bytes = bytes;
+        idx->hbm_bytes += bytes;
+        const int64_t items = n_tiles * kSM * (dim / 8);
+        split_images_kernel<<<(unsigned)((items + 255) / 256), 256, 0, st>>>(
+            idx->d_emb, n, dim, static_cast<unsigned char *>(idx->d_split_img));
+    }
+    if (!idx->d_bq_img) ANRAG_HIP(hipMalloc(&idx->d_bq_img, (size_t)qelems * 4));
+    split_images_kernel<<<(unsigned)((kBQ * (dim / 8) + 255) / 256), 256, 0, st>>>(
+        idx->d_bq, kBQ, dim, static_cast<unsigned char *>(idx->d_bq_img));
     if (!idx->d_bq_hi) {
         ANRAG_HIP(hipMalloc(&idx->d_bq_hi, (size_t)qelems * 2));
         ANRAG_HIP(hipMalloc(&idx->d_bq_lo, (size_t)qelems * 2));
@@ -241,13 +463,15 @@ int batched_passes_split(anrag_index *idx, hipStream_t st, int32_t nq, int32_t k
     else
         dense_batched_split_kernel<true, false><<<grid_for(n_sample), kSplitThreads, kSplitLdsBytes, st>>>(
             idx->d_emb, qh, ql, dim, nq, n_sample, stride, nullptr, idx->d_bsample, nullptr, nullptr, 0, nullptr, nullptr);
-    batched_threshold_kernel<<<nq, 64, 0, st>>>(idx->d_bsample, n_sample, k, idx->d_btau, idx->d_bcnt);
+    batched_threshold_kernel<<<nq, kThrWaves * 64, 0, st>>>(idx->d_bsample, n_sample, k, idx->d_btau, idx->d_bcnt);
+    const unsigned char *e_img = static_cast<const unsigned char *>(idx->d_split_img);
+    const unsigned char *q_img = static_cast<const unsigned char *>(idx->d_bq_img);
     if (allow)
-        dense_batched_split_kernel<false, true><<<grid_for(n), kSplitThreads, kSplitLdsBytes, st>>>(
-            idx->d_emb, qh, ql, dim, nq, n, 1, idx->d_btau, nullptr, idx->d_bcnt, cand, kCandCap, idx->d_dense_src, allow);
+        dense_batched_split_dma_kernel<true><<<grid_for(n), kSplitThreads, kDmaLdsTotal, st>>>(
+            e_img, q_img, dim / kDK, nq, n, idx->d_btau, idx->d_bcnt, cand, kCandCap, idx->d_dense_src, allow);
     else
-        dense_batched_split_kernel<false, false><<<grid_for(n), kSplitThreads, kSplitLdsBytes, st>>>(
-            idx->d_emb, qh, ql, dim, nq, n, 1, idx->d_btau, nullptr, idx->d_bcnt, cand, kCandCap, nullptr, nullptr);
+        dense_batched_split_dma_kernel<false><<<grid_for(n), kSplitThreads, kDmaLdsTotal, st>>>(
+            e_img, q_img, dim / kDK, nq, n, idx->d_btau, idx->d_bcnt, cand, kCandCap, nullptr, nullptr);
     ANRAG_HIP(hipGetLastError());
     return ANRAG_OK;
 }

@@ -28,7 +28,7 @@ got = out.cpu().numpy()
 print("flags:", int(flag.abs().sum().item()), " ids match torch:", np.array_equal(got[:, :, 1], ref.indices.cpu().numpy()),
       " max|dscore|:", float(np.abs(got[:, :, 0].copy().view(np.float64) - ref.values.cpu().numpy()).max()))
 idx.profile(True, kernels=[nat.KERNEL_DENSE_BATCHED]); idx.profile_reset()
-iters = 10
+iters = int(os.environ.get("ITERS", "10"))
 t0 = time.perf_counter()
 for _ in range(iters): run()
 idx.sync(); wall = (time.perf_counter() - t0) / iters

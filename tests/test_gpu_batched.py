@@ -92,3 +92,83 @@ def test_split_precision_option(corpus):
     assert worst <= 5e-5, worst
     assert (doc == doc32).mean() > 0.99
     print(f"bf16x3 max |score - f32 oracle| over {nq * k} results: {worst:.2e}")
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16x3"])
+def test_exactly_k_rows_stand_out(mode):
+    """Adversarial for the sampled threshold: only k rows score high for a query and none of them need be in the
+    sample.  The threshold is then the k-th best of ORDINARY rows -- still a lower bound -- and all k planted rows must
+    come back, in both arithmetic modes (the sampled and the full pass of a mode score a row bit-identically, so a
+    sampled row can never fall just below its own threshold)."""
+    from oracle import ref_search
+    from anrag.index import Index
+
+    rng = np.random.default_rng(11)
+    n, d, nq, k = 66_003, 128, 48, 10
+    e = rng.standard_normal((n, d), dtype=np.float32)
+    e /= np.linalg.norm(e, axis=1, keepdims=True)
+    q = rng.standard_normal((nq, d), dtype=np.float32)
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    planted = rng.choice(n, size=(nq, k), replace=False)
+    for qi in range(nq):
+        for j, r in enumerate(planted[qi]):
+            v = q[qi] + (0.02 + 0.01 * j) * rng.standard_normal(d, dtype=np.float32)
+            e[r] = v / np.linalg.norm(v)
+    with Index(0) as idx:
+        idx.dense_load(e)
+        idx.set_batched_precision(mode)
+        doc, score, count = idx.dense_search(q, k)
+    for qi in range(nq):
+        assert int(count[qi]) == k
+        assert set(doc[qi].tolist()) == set(planted[qi].tolist()), qi
+        full = ref_search.dense_scores(q[qi], e)
+        want = ref_search.canonical_topk(full, k)
+        assert_ranking_matches(want, full[want], doc[qi], score[qi], 1e-4, full, f"{mode} q{qi}")
+
+
+def test_split_precision_filter_nan_reload():
+    """The split-precision full pass (LDS-DMA images of the corpus): source filter, a NaN row (ranks first, like numpy's
+    argsort puts it and like K1), a tail tile (rows not a multiple of 256), 17 queries (15/16 of the block is padding)
+    and a second dense_load on the same index (the images must be rebuilt, not reused)."""
+    from oracle import ref_search
+    from anrag.index import Index
+
+    rng = np.random.default_rng(12)
+    n, d, nq, k = 65_536 + 77, 256, 17, 12
+    e = rng.standard_normal((n, d), dtype=np.float32)
+    e /= np.linalg.norm(e, axis=1, keepdims=True)
+    e2 = rng.standard_normal((n + 300, d), dtype=np.float32)
+    e2 /= np.linalg.norm(e2, axis=1, keepdims=True)
+    q = e[rng.integers(0, n, nq)] + 0.05 * rng.standard_normal((nq, d), dtype=np.float32)
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    sources = (np.arange(n) % 7).astype(np.uint16)
+    allow = np.array([1, 1, 0, 1, 0, 0, 1], dtype=np.uint8)
+    with Index(0) as idx:
+        idx.dense_load(e, source_id=sources)
+        idx.set_batched_precision("bf16x3")
+        for al in (None, allow):
+            doc, score, count = idx.dense_search(q, k, al)
+            keep = np.ones(n, bool) if al is None else al[sources].astype(bool)
+            for qi in range(nq):
+                full = ref_search.dense_scores(q[qi], e)
+                want = ref_search.canonical_topk(full, k, keep)
+                assert int(count[qi]) == k
+                assert_ranking_matches(want, full[want], doc[qi], score[qi], 1e-4, full, f"q{qi}")
+        # a NaN row
+        e_nan = e.copy()
+        e_nan[40_000, 3] = np.nan
+        idx.dense_load(e_nan)
+        doc, score, count = idx.dense_search(q, k)
+        assert np.all(doc[:, 0] == 40_000) and np.all(np.isinf(score[:, 0]))
+        for qi in range(nq):
+            full = ref_search.dense_scores(q[qi], e)
+            full[40_000] = -np.inf
+            want = ref_search.canonical_topk(full, k - 1)
+            assert_ranking_matches(want, full[want], doc[qi, 1:], score[qi, 1:], 1e-4, full, f"nan q{qi}")
+        # another corpus on the same index
+        idx.dense_load(e2)
+        doc, score, count = idx.dense_search(q, k)
+        for qi in range(nq):
+            full = ref_search.dense_scores(q[qi], e2)
+            want = ref_search.canonical_topk(full, k)
+            assert_ranking_matches(want, full[want], doc[qi], score[qi], 1e-4, full, f"reload q{qi}")
