@@ -124,7 +124,18 @@ __global__ __launch_bounds__(BatchGeom<QW>::kThreads, 2) void dense_batched_kern
         float *es = lds + buf * kBufFloats;
         const int f = tid + (j < NE ? j : j - NE) * kBatchThreads;
         float *dst = (j < NE ? es : es + kBM * kLdk) + (f >> 3) * kLdk + (f & 7) * 4;
-        *reinterpret_cast<f32x4 *>(dst) = j < NE ? stage_e[j] : stage_q[j - NE];
+        if (j < NE) {
+            *reinterpret_cast<f32x4 *>(dst) = stage_e[j];
+        } else {
+            // query rows are stored with every group of four k rotated by two: the MFMA of k-slot s then takes A from
+            // register s and B from register (s + 2) & 3 of their (4-aligned) fragment tuples -- different VGPR banks.
+            // With A and B in the same bank the pass ran up to 20 % slower, depending on what else the register
+            // allocator happened to do (measured on three functionally identical builds: 3.09 / 3.50 / 3.73 ms).
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            const f32x4 x = stage_q[j - NE];
+            *reinterpret_cast<f32x2 *>(dst) = f32x2{x[2], x[3]};
+            *reinterpret_cast<f32x2 *>(dst + 2) = f32x2{x[0], x[1]};
+        }
     };
     auto load_stage = [&]() {
 #pragma unroll
@@ -188,7 +199,7 @@ __global__ __launch_bounds__(BatchGeom<QW>::kThreads, 2) void dense_batched_kern
                 for (int ti = 0; ti < 2; ++ti)
 #pragma unroll
                     for (int tj = 0; tj < 2; ++tj)
-                        acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][ti][s], fb[cur][tj][s], acc[ti][tj], 0, 0, 0);
+                        acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][ti][s], fb[cur][tj][(s + 2) & 3], acc[ti][tj], 0, 0, 0);
                 // staging slots: (0,0..1) write last step's registers to LDS, (0,2..3) refill them -- as early in
                 // the step as the order store -> load allows, so a load has almost a whole step to land
                 if (g == 0) {
@@ -204,16 +215,16 @@ __global__ __launch_bounds__(BatchGeom<QW>::kThreads, 2) void dense_batched_kern
             }
         }
         if (++cur_ks == ksteps) {
-            batched_tile_epilogue<SAMPLE, FILTER>(acc, cur_tile, rw, qw, qbase, l31, lh, my_tau, n_work, stride, nq,
-                                                  sample_scores, cnt, cand, cap, src, allow_bits, slice,
-                                                  Geo::kSurvEntries, surv_fill);
+            batched_tile_epilogue<SAMPLE, FILTER, 2, Geo::kSurvEntries>(acc, cur_tile, rw, qw, qbase, l31, lh, my_tau,
+                                                                        n_work, stride, nq, sample_scores, cnt, cand, cap,
+                                                                        src, allow_bits, slice, surv_fill);
             cur_ks = 0;
             cur_tile += tile_step;
         }
         __syncthreads();
     }
     if constexpr (!SAMPLE) {
-        if (surv_fill) flush_survivors(slice, Geo::kSurvEntries, surv_fill, cnt, cand, cap);
+        if (surv_fill) flush_survivors(slice, Geo::kSurvEntries, surv_fill, cnt, cand);
     }
 }
 
@@ -299,7 +310,8 @@ __global__ __launch_bounds__(64) void batched_select_kernel(const Cand32 *__rest
 
 // ------------------------------------------------------------------ host side
 bool batched_path_applies(const anrag_index *idx, int32_t n_queries, int32_t k) {
-    return n_queries >= 16 && k <= ANRAG_FUSED_K_MAX && idx->dim % kBK == 0 && idx->n_rows >= 65536;
+    return n_queries >= 16 && k <= ANRAG_FUSED_K_MAX && idx->dim % kBK == 0 && idx->n_rows >= 65536 &&
+           idx->n_rows < 0xffffffffLL;  // survivor records carry 32-bit rows
 }
 
 static int ensure_batched_workspace(anrag_index *idx, int64_t n_sample) {

@@ -34,8 +34,11 @@ __device__ __forceinline__ SurvBuf surv_buf(unsigned char *slice, int entries) {
     return {reinterpret_cast<float *>(slice), reinterpret_cast<uint32_t *>(slice + entries * 4), slice + entries * 8};
 }
 
+// (Few, narrow arguments on purpose, here and below: one argument more than fit the argument registers went through
+// the stack, which turns on scratch memory for the whole kernel -- the f32 full pass ran 20 % slower for it.)
 static __device__ __noinline__ void flush_survivors(unsigned char *slice, int entries, int n, int32_t *__restrict__ cnt,
-                                                    Cand32 *__restrict__ cand, int32_t cap) {
+                                                    Cand32 *__restrict__ cand) {
+    constexpr int32_t cap = kCandCap;
     const SurvBuf b = surv_buf(slice, entries);
     for (int i = lane_id(); i < n; i += kWave) {
         const int q = b.q[i];
@@ -52,22 +55,21 @@ static __device__ __noinline__ void flush_survivors(unsigned char *slice, int en
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 }
 
-// The per-score path for one 32 x 32 accumulator tile that holds at least one survivor (lane = query column q with
-// threshold tau_q -- +huge for a padding query; register r = row row0 + (r&3) + 8*(r>>2), row0 includes 4 * lane half).
-// Returns the wave's new fill.
-template <bool FILTER>
-__device__ __noinline__ int tile_survivors(f32x16 v, int64_t row0, int q, int32_t nq, float tau_q, int64_t n_work,
-                                           unsigned char *slice, int entries, int fill, int32_t *__restrict__ cnt,
-                                           Cand32 *__restrict__ cand, int32_t cap, const uint16_t *__restrict__ src,
+// The per-score path for one 32 x 32 accumulator tile that holds at least one survivor (lane = query column q -- -1
+// for a padding query: a NaN / inf row scores NaN against the zero rows of the query block too -- with threshold
+// tau_q; register r = row row0 + (r&3) + 8*(r>>2), row0 includes 4 * lane half).  Returns the wave's new fill.
+template <bool FILTER, int ENTRIES>
+__device__ __noinline__ int tile_survivors(f32x16 v, uint32_t row0, int q, float tau_q, uint32_t n_work,
+                                           unsigned char *slice, int fill, int32_t *__restrict__ cnt,
+                                           Cand32 *__restrict__ cand, const uint16_t *__restrict__ src,
                                            const uint32_t *__restrict__ allow_bits) {
-    const SurvBuf b = surv_buf(slice, entries);
+    const SurvBuf b = surv_buf(slice, ENTRIES);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         float s = v[r];
         if (__builtin_amdgcn_ballot_w64(!(s < tau_q)) == 0) continue;  // !(s < tau): survivors and NaNs
-        const int64_t wr = row0 + (r & 3) + 8 * (r >> 2);
-        // q < nq: a NaN / inf row scores NaN against the zero rows of the query block too
-        bool ok = !(s < tau_q) && wr < n_work && q < nq;
+        const uint32_t wr = row0 + (r & 3) + 8 * (r >> 2);
+        bool ok = !(s < tau_q) && wr < n_work && q >= 0;
         if constexpr (FILTER) {
             if (ok) ok = source_ok(allow_bits, src[wr]);
         }
@@ -76,12 +78,12 @@ __device__ __noinline__ int tile_survivors(f32x16 v, int64_t row0, int q, int32_
         if (ok) {
             const int at = fill + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
             b.score[at] = s;
-            b.row[at] = (uint32_t)wr;
+            b.row[at] = wr;
             b.q[at] = (uint8_t)q;
         }
         fill += __builtin_popcountll(m);
-        if (fill > entries - kWave) {
-            flush_survivors(slice, entries, fill, cnt, cand, cap);
+        if (fill > ENTRIES - kWave) {
+            flush_survivors(slice, ENTRIES, fill, cnt, cand);
             fill = 0;
         }
     }
@@ -92,14 +94,14 @@ __device__ __noinline__ int tile_survivors(f32x16 v, int64_t row0, int q, int32_
 // column, 16 rows per register set (32x32 C/D map: row = (r&3) + 8*(r>>2) + 4*(lane>>5)).  SAMPLE: store every
 // score of the sampled rows; otherwise 16 compares per accumulator tile, and the per-score path above only for a tile
 // that holds a survivor (my_tau must be +huge for padding queries).  Zeroes the accumulators.
-template <bool SAMPLE, bool FILTER, int TI = 2>
+template <bool SAMPLE, bool FILTER, int TI = 2, int ENTRIES = 448>
 __device__ __forceinline__ void batched_tile_epilogue(f32x16 (&acc)[TI][2], int64_t tile, int rw, int qw, int qbase,
                                                       int l31, int lh, const float (&my_tau)[2], int64_t n_work,
                                                       int64_t stride, int32_t nq, float *__restrict__ sample_scores,
                                                       int32_t *__restrict__ cnt, Cand32 *__restrict__ cand, int32_t cap,
                                                       const uint16_t *__restrict__ src,
                                                       const uint32_t *__restrict__ allow_bits, unsigned char *slice,
-                                                      int entries, int &fill) {
+                                                      int &fill) {
     // a workgroup tile is 2 (row halves) x TI x 32 corpus rows: TI = 2 -> 128 rows (kBM), TI = 4 -> 256 rows
 #pragma unroll
     for (int ti = 0; ti < TI; ++ti)
@@ -130,8 +132,8 @@ __device__ __forceinline__ void batched_tile_epilogue(f32x16 (&acc)[TI][2], int6
 #pragma unroll
                 for (int r = 0; r < 16; ++r) hit |= !(acc[ti][tj][r] < my_tau[tj]);
                 if (__builtin_amdgcn_ballot_w64(hit) != 0)
-                    fill = tile_survivors<FILTER>(acc[ti][tj], row0, q, nq, my_tau[tj], n_work, slice, entries, fill, cnt,
-                                                  cand, cap, src, allow_bits);
+                    fill = tile_survivors<FILTER, ENTRIES>(acc[ti][tj], (uint32_t)row0, q < nq ? q : -1, my_tau[tj],
+                                                           (uint32_t)n_work, slice, fill, cnt, cand, src, allow_bits);
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[ti][tj][r] = 0.f;

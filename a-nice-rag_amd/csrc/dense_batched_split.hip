@@ -203,7 +203,7 @@ __global__ __launch_bounds__(kSplitThreads, 2) void dense_batched_split_kernel(
         if (++cur_ks == ksteps) {
             int no_fill = 0;
             batched_tile_epilogue<SAMPLE, FILTER, 4>(acc, cur_tile, rw, qw, 0, l31, lh, my_tau, n_work, stride, nq,
-                                                     sample_scores, cnt, cand, cap, src, allow_bits, nullptr, 0, no_fill);
+                                                     sample_scores, cnt, cand, cap, src, allow_bits, nullptr, no_fill);
             cur_ks = 0;
             cur_tile += tile_step;
         }
@@ -359,8 +359,8 @@ __global__ __launch_bounds__(kSplitThreads, 2) void dense_batched_split_dma_kern
     auto step_done = [&]() {
         if (++cur_ks < ksteps) return;
         cur_ks = 0;
-        batched_tile_epilogue<false, FILTER, 4>(acc, cur_tile, rw, qw, 0, l31, lh, my_tau, n_work, 1, nq, nullptr, cnt, cand,
-                                                cap, src, allow_bits, slice, kSurvEntries, surv_fill);
+        batched_tile_epilogue<false, FILTER, 4, kSurvEntries>(acc, cur_tile, rw, qw, 0, l31, lh, my_tau, n_work, 1, nq,
+                                                              nullptr, cnt, cand, cap, src, allow_bits, slice, surv_fill);
         cur_tile += tile_step;
     };
 
@@ -411,7 +411,7 @@ __global__ __launch_bounds__(kSplitThreads, 2) void dense_batched_split_dma_kern
     }
 #undef ANRAG_K2_BAR
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the trailing copies must not outlive the workgroup's LDS
-    if (surv_fill) flush_survivors(slice, kSurvEntries, surv_fill, cnt, cand, cap);
+    if (surv_fill) flush_survivors(slice, kSurvEntries, surv_fill, cnt, cand);
 }
 
 __global__ void batched_threshold_kernel(const float *, int64_t, int32_t, float *, int32_t *);  // dense_batched.hip
