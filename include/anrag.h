@@ -166,8 +166,10 @@ int anrag_dense_search_batch_device(anrag_index *idx, const float *d_queries, in
 /* Arithmetic of the batched path.  0 (default): exact f32 products and sums on the f32 matrix cores.
  * 1: split-precision -- every operand as hi + lo bf16, three bf16 MFMAs per product (hi.hi + hi.lo + lo.hi),
  * f32 accumulation: scores within ~3e-5 of the f32 result for unit-norm vectors (inside the 1e-4 bar, not
- * bit-equal), the pass HBM/MFMA balanced instead of MFMA-bound.  Applies to passes of any size (the query
- * block is padded to 256). */
+ * bit-equal), ~2.7x the throughput of mode 0.  Applies to passes of any size (the query block is padded to
+ * 256).  MEMORY: the first mode-1 pass after a dense load builds a second copy of the corpus as bf16 hi / lo
+ * images (4 bytes per element, i.e. the corpus size again; counted in anrag_index_stats' hbm_bytes); it is
+ * dropped by the next anrag_dense_load / anrag_index_destroy, not by switching back to mode 0. */
 int anrag_set_batched_precision(anrag_index *idx, int32_t mode);
 
 /* All N scores of one query (what search_engine.py:81 materialises), for tests
