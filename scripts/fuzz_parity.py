@@ -111,6 +111,58 @@ def run(budget: float = 60.0, seed: int = 0) -> int:
     return checks
 
 
+def run_batched(budget: float = 60.0, seed: int = 0) -> int:
+    """K2 (16+ queries per call on the matrix cores, corpora of 65,536+ rows), both arithmetic modes: random sizes with
+    tail tiles, dims (multiples of 32), query counts incl. 256+ (two passes) and counts that leave most of the block
+    padding, k up to 64, source filters, duplicated rows (exact ties), CLUSTERED corpora (near-duplicates of a few
+    centres: the sampled threshold sits in a dense score region and lists run long or overflow into the K1 redo).
+    Every score within 1e-4 of the oracle's, rows exact outside near-ties, counts exact."""
+    rng = np.random.default_rng(seed)
+    t_end = time.time() + budget
+    rounds = checks = 0
+    while time.time() < t_end:
+        rounds += 1
+        n = int(rng.choice([65536, 65537, 70001, 100_000, 131_072 + 255, 200_003]))
+        d = int(rng.choice([32, 64, 128, 256, 384, 768]))
+        n_src = int(rng.integers(2, 9))
+        kind = rng.choice(["normal", "ties", "clustered"])
+        if kind == "clustered":
+            centres = rng.standard_normal((int(rng.integers(3, 40)), d), dtype=np.float32)
+            e = centres[rng.integers(0, len(centres), size=n)] + np.float32(rng.choice([1e-3, 0.05, 0.3])) * rng.standard_normal((n, d), dtype=np.float32)
+        else:
+            e = rng.standard_normal((n, d), dtype=np.float32)
+            if kind == "ties":
+                originals = e[rng.integers(0, n, size=4)].copy()
+                e[rng.integers(0, n, size=n // 8)] = originals[rng.integers(0, 4, size=n // 8)]
+        e /= np.maximum(np.linalg.norm(e, axis=1, keepdims=True), 1e-12)
+        sid = rng.integers(0, n_src, size=n).astype(np.uint16)
+        log("K2 corpus", rounds, "n", n, "d", d, kind)
+        with Index(0) as idx:
+            idx.dense_load(e, source_id=sid)
+            for trial in range(3):
+                mode = "bf16x3" if rng.random() < 0.6 else "f32"
+                nq = int(rng.choice([16, 17, 33, 100, 128, 129, 200, 256, 300]))
+                k = int(rng.choice([1, 5, 10, 25, 64]))
+                allow = None if rng.random() < 0.5 else (rng.random(n_src) < 0.6).astype(np.uint8)
+                if allow is not None and not allow.any():
+                    allow[0] = 1
+                mask = None if allow is None else allow[sid].astype(bool)
+                q = e[rng.integers(0, n, size=nq)] + 0.1 * rng.standard_normal((nq, d)).astype(np.float32)
+                q[0] = rng.standard_normal(d).astype(np.float32)
+                log("  trial", trial, mode, "nq", nq, "k", k, "filter", allow is not None)
+                idx.set_batched_precision(mode)
+                doc, score, count = idx.dense_search(q, k, allow)
+                for qi in range(nq):
+                    full = ref_search.dense_scores(q[qi], e)
+                    want = ref_search.canonical_topk(full, k, mask)
+                    m = int(count[qi])
+                    assert m == len(want), (mode, qi, m, len(want))
+                    assert_ranking_matches(want, full[want], doc[qi, :m], score[qi, :m], 1e-4, full, f"K2 {mode} r{rounds} q{qi}")
+                    checks += 1
+    log("K2 done", rounds, checks)
+    return checks
+
+
 def run_big(budget: float = 60.0, seed: int = 0) -> int:
     """BM25 on corpora of 262k .. 1.2M documents (partitions of 1,280 .. 4,096 documents: the 1,024-thread form of
     K3, which the corpora of run() never reach), built on the GPU (anrag.synth), against the oracle's CSR scorer:
@@ -168,5 +220,7 @@ if __name__ == "__main__":
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     if len(sys.argv) > 3 and sys.argv[3] == "big":
         run_big(budget, seed)
+    elif len(sys.argv) > 3 and sys.argv[3] == "batched":
+        print("K2 fuzz ok:", run_batched(budget, seed), "query checks")
     else:
         run(budget, seed)

@@ -25,3 +25,8 @@ def test_seeded_fuzz_against_the_oracle():
 def test_seeded_fuzz_of_bm25_on_large_partitions():
     """262k .. 1.2M documents: the 1,024-thread form of K3 (partitions of 1,280 .. 4,096 documents)."""
     assert _fuzzer().run_big(budget=15.0, seed=20261) >= 10
+
+
+def test_seeded_fuzz_of_the_batched_path():
+    """65k .. 200k rows, 16 .. 300 queries per call, both K2 arithmetic modes, filters, ties, clustered corpora."""
+    assert _fuzzer().run_batched(budget=25.0, seed=20262) >= 300
