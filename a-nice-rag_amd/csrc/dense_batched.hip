@@ -128,9 +128,11 @@ __global__ __launch_bounds__(BatchGeom<QW>::kThreads, 2) void dense_batched_kern
             *reinterpret_cast<f32x4 *>(dst) = stage_e[j];
         } else {
             // query rows are stored with every group of four k rotated by two: the MFMA of k-slot s then takes A from
-            // register s and B from register (s + 2) & 3 of their (4-aligned) fragment tuples -- different VGPR banks.
-            // With A and B in the same bank the pass ran up to 20 % slower, depending on what else the register
-            // allocator happened to do (measured on three functionally identical builds: 3.09 / 3.50 / 3.73 ms).
+            // register s and B from register (s + 2) & 3 of their (4-aligned) fragment tuples.  Three functionally
+            // identical builds of this kernel ran 3.09 / 3.50 / 3.73 ms depending only on the registers the compiler
+            // picked for the fragments (A and B of every MFMA in the same VGPR bank in all three); with this pairing
+            // every build since has run 3.12-3.15 ms.  Why is not established (a bare MFMA loop does not care:
+            // scripts/exp/mfma_f32_banks.hip).
             typedef float f32x2 __attribute__((ext_vector_type(2)));
             const f32x4 x = stage_q[j - NE];
             *reinterpret_cast<f32x2 *>(dst) = f32x2{x[2], x[3]};
