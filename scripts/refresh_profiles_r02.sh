@@ -33,13 +33,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
   find $O/pmc_$c -name "*counter_collection.csv" -exec cp {} $O/pmc_${c}_dense_1Mx768.csv \;
 done
 echo "pmc K1 done"
-# 4. K2: MFMA pipe counters, f32 and bf16x3
-for p in f32 bf16x3; do
-  rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_k2_$p -o k2 -- \
-    python3 $R/scripts/microbench_batched.py 1000000 768 256 10 $p > $O/pmc_k2_$p.txt 2> $O/pmc_k2_$p.err
-  find $O/pmc_k2_$p -name "*counter_collection.csv" -exec cp {} $O/pmc_k2_${p}.csv \;
-done
-echo "pmc K2 done"
+# 4. K2 has its own scripts: scripts/refresh_profiles_k2.sh + scripts/summarise_k2.py
 # the raw traces are big: keep the summaries only
-rm -rf $O/prof_bench $O/prof_k3 $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/pmc_k2_f32 $O/pmc_k2_bf16x3
+rm -rf $O/prof_bench $O/prof_k3 $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE
 ls -la $O

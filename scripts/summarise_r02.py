@@ -75,25 +75,7 @@ k3 = {"kernel": name, "commit": commit, "docs": 1000000, "calls": calls, "avg_us
       "command": "rocprofv3 --kernel-trace --stats -- python3 scripts/microbench_bm25.py 1000000 400 (idle GPU, one launch per query)"}
 json.dump(k3, open(os.path.join(DST, "r02_k3_bm25_1M.json"), "w"), indent=1)
 
-for p in ("f32", "bf16x3"):
-    path = os.path.join(SRC, f"pmc_k2_{p}.csv")
-    kern = "dense_batched_split_kernel<false, false>" if p == "bf16x3" else "dense_batched_kernel<256, false, false>"
-    out = {"kernel": kern + " (K2 filter pass, 256 queries x 1M x 768)", "commit": commit,
-           "command": f"rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace -- python3 "
-                      f"scripts/microbench_batched.py 1000000 768 256 10 {p}"}
-    for c in ("SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "GRBM_GUI_ACTIVE"):
-        v = pmc(path, kern, c)
-        out[c] = statistics.median(x for x, _ in v)
-        out["kernel_us_profiled"] = statistics.median(t for _, t in v) / 1e3
-        out["dispatches"] = len(v)
-    clk = out["GRBM_GUI_ACTIVE"] / 8 / (out["kernel_us_profiled"] * 1e-6) / 1e9
-    out["derived"] = {"effective_clock_GHz": clk,
-                      "mfma_pipe_utilisation": out["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * out["GRBM_GUI_ACTIVE"] / 8),
-                      "note": "busy cycles summed over the 1,024 SIMDs / (SIMDs x kernel cycles); GRBM_GUI_ACTIVE is the sum over the 8 XCDs"}
-    out["microbench_line_under_the_profiler"] = open(os.path.join(SRC, f"pmc_k2_{p}.txt")).read().strip().splitlines()[-1]
-    json.dump(out, open(os.path.join(DST, f"r02_pmc_k2_{p}.json"), "w"), indent=1)
+# (K2: scripts/summarise_k2.py)
 print(json.dumps(rec, indent=1)); print(json.dumps(k3, indent=1))
-for p in ("f32", "bf16x3"):
-    print(open(os.path.join(DST, f"r02_pmc_k2_{p}.json")).read())
 for k, v in bench_stats.items():
     print(f"{v[0]:6d} x {v[1] / 1e3:9.1f} us  {k[:90]}")
