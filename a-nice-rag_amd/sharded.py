@@ -127,6 +127,10 @@ class ShardedSearcher:
         self.recv = [mk(self.world, self.group, 2 * self.k) for _ in range(self.depth)]
         self.out = [mk(self.group, self.top_n) for _ in range(self.depth)]
         self.count = [torch.zeros(self.group, dtype=torch.int32, device=self.device) for _ in range(self.depth)]
+        if self.cuda:
+            # torch zero-fills these on ITS stream; the engine writes them on its own streams: the fills must be over
+            # before the first query (a late fill would wipe an answer)
+            torch.cuda.synchronize(self.device)
         self._slot = 0
         self._filled = 0
         self._grouped = self.group > 1 and hasattr(engine, "legs_group")

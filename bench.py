@@ -288,6 +288,7 @@ def run_rank(args) -> int:
     if not sharded:
         out = torch.zeros((args.queries, TOPN, 2), dtype=torch.int64, device=device)
         cnt = torch.zeros(args.queries, dtype=torch.int32, device=device)
+        torch.cuda.synchronize()  # (torch fills on its own stream; the library writes on its streams)
         allow_ptr = d_allow.data_ptr() if d_allow is not None else None
 
         def step(i):
@@ -526,6 +527,7 @@ def check_against_single_index(args, synth, Index, nat, lib, device, local_rank,
                   synth.BM25_K1, synth.BM25_B, source_id=src1)
     out = torch.zeros((nq, TOPN, 2), dtype=torch.int64, device=device)
     cnt = torch.zeros(nq, dtype=torch.int32, device=device)
+    torch.cuda.synchronize()  # torch's zero fills run on its own stream: they must not land after the library's answers
     ap = d_allow.data_ptr() if d_allow is not None else None
     for qi in range(nq):
         nat.check(lib.anrag_hybrid_search_device(one.handle, Q[qi].data_ptr(), T[qi].data_ptr(), n_terms[qi], K,
@@ -562,6 +564,7 @@ def also_measurements(args, torch, nat, lib, idx, Index, synth, E, Q, T, n_terms
     def k1_pass(sub, rows, group, steps):
         qn = Q.shape[0]
         outb = torch.zeros((qn, TOPN, 2), dtype=torch.int64, device=device)
+        torch.cuda.synchronize()
         def run(n):
             for i in range(0, n, group):
                 qi = i % qn
@@ -604,6 +607,9 @@ def also_measurements(args, torch, nat, lib, idx, Index, synth, E, Q, T, n_terms
         outb = torch.zeros((256, TOPN, 2), dtype=torch.int64, device=device)
         flag = torch.zeros(256, dtype=torch.int32, device=device)
         ref = torch.zeros((4, TOPN, 2), dtype=torch.int64, device=device)
+        # torch fills these on ITS stream; the library writes them on its own streams: without this the zero fill of
+        # `ref` could land after K1's answer (it did, once the passes above it changed the timing)
+        torch.cuda.synchronize()
         nat.check(lib.anrag_dense_search_device(idx.handle, Qb.data_ptr(), 4, TOPN, None, ref.data_ptr()))
         idx.sync()
         for mode in ("f32", "bf16x3"):
@@ -637,6 +643,7 @@ def also_measurements(args, torch, nat, lib, idx, Index, synth, E, Q, T, n_terms
     if post is not None:
         qn = Q.shape[0]
         outk = torch.zeros((qn, K, 2), dtype=torch.int64, device=device)
+        torch.cuda.synchronize()
         df = np.diff(post["indptr"])
         touched = [int(sum(int(df[t]) for t in T[i, : n_terms[i]].cpu().tolist() if t >= 0)) for i in range(qn)]
         def run(n):
