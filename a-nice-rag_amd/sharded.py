@@ -70,7 +70,10 @@ class HipShardEngine:
         bits = np.zeros(65536, dtype=np.uint8)
         a = np.asarray(allow_source, dtype=np.uint8)
         bits[: a.size] = a != 0
-        return torch.from_numpy(np.packbits(bits, bitorder="little").view(np.int32).copy()).to(self.device)
+        t = torch.from_numpy(np.packbits(bits, bitorder="little").view(np.int32).copy()).to(self.device)
+        if t.is_cuda:
+            torch.cuda.synchronize(t.device)  # the copy runs on torch's stream, the kernels that read it on the index's
+        return t
 
     @staticmethod
     def _ptr(t: Optional[torch.Tensor]):
