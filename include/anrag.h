@@ -17,6 +17,12 @@
  *     shim maps error codes back to that).
  *   - "host" pointers are ordinary process memory; "device" pointers are HBM
  *     addresses of the index's GPU (hipMalloc / torch tensor .data_ptr()).
+ *     The *_device entry points enqueue on the index's streams and return: a
+ *     device INPUT must be complete before the call, and so must any pending
+ *     write of the caller's to a device OUTPUT (a framework's zero fill of a
+ *     fresh tensor runs on the framework's stream and can land after the answer):
+ *     synchronise the producing stream first, or hand the index your streams
+ *     (anrag_index_set_streams).
  *   - one anrag_index = one GPU's shard: a row block of the corpus matrix and
  *     the postings of the same documents.  Calls on one index are serialised by
  *     an internal mutex (the reference shares one SearchEngine between Streamlit
