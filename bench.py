@@ -781,6 +781,10 @@ def niceqa_recall():
     return {"gpu": rg["recall_at_10"], "cpu_reference": rc["recall_at_10"], "equal": rg == rc,
             "questions": rg["questions"], "with_gold_chunk": rg["with_gold_chunk"],
             "identical_top10_lists": sum(a == b for a, b in zip(gpu, cpu)),
+            # the rest: near-ties of the fp32 dense scores (host BLAS and the scan sum in different orders; the dense
+            # bar is 1e-4) move a candidate by a rank, and with it its RRF term
+            "differing_lists_with_the_same_10_ids": sum(a != b and set(a) == set(b) for a, b in zip(gpu, cpu)),
+            "ids_in_one_list_only_max": max([len(set(a) ^ set(b)) // 2 for a, b in zip(gpu, cpu)] or [0]),
             "corpus": "stand-in: 9,609 shipped chunk ids x 384-d hashed-BoW embeddings (no encoder weights offline)"}
 
 
