@@ -658,8 +658,8 @@ int launch_bm25_lists(anrag_index *idx, hipStream_t st, const int32_t *d_terms, 
     uint32_t *blk_r = idx->d_blk_row_b + (int64_t)set * idx->n_parts * kListLen;
     {
         LaunchTimer t(idx, ANRAG_KERNEL_BM25, st);
-    static const bool force_large = getenv("ANRAG_K3_LARGE") != nullptr;  // experiment knob: always 1,024 threads
-    const bool small = !force_large && idx->part_docs <= kPostPerThread * kBm25ThreadsSmall;
+        // partitions of <= 1,024 documents: the 256-thread form (one wave per SIMD, cheaper barriers)
+        const bool small = idx->part_docs <= kPostPerThread * kBm25ThreadsSmall;
 #define ANRAG_BM25_T(F, S, T)                                                                                     \
     bm25_kernel<F, S, T><<<idx->n_parts, T, bm25_lds_bytes(T), st>>>(                                              \
         idx->d_indptr, idx->d_post_doc, idx->d_post_impact, idx->d_idf, idx->d_part_slot, idx->d_part_ptr,        \

@@ -273,9 +273,6 @@ __global__ __launch_bounds__(kThrWaves * 64) void batched_threshold_kernel(const
     block_merge(top, lds_s, lds_r, kThrWaves);
     if (threadIdx.x == 0) {
         tau[q] = top.thr_r == kNoRow ? neg_inf<float>() : top.thr_s;
-#if defined(K2_EXP) && K2_EXP == 3
-        tau[q] = 3e38f;  // experiment: no survivors at all
-#endif
         cnt[q] = 0;
     }
 }
