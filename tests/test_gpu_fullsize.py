@@ -214,3 +214,33 @@ def test_hybrid_consistent_at_full_size(world):
         bl = idx.bm25_search(terms[qi], 25)[0].tolist()
         want = ref_search.weighted_reciprocal_rank_fusion([(dl, "d"), (bl, "b")], {"d": 5.0, "b": 1.0}, 40)[:10]
         assert ids.tolist() == [i for i, _ in want] and scores.tolist() == [s for _, s in want]
+
+
+def test_c4_with_a_source_filter_at_full_size(world):
+    """BASELINE configs[3] (256 queries x 1M x 768) under a source filter, both K2 arithmetic modes: the filtered
+    epilogues of dense_batched_kernel<256> and dense_batched_split_dma_kernel at the full size, against torch.topk
+    over the allowed rows."""
+    from anrag.index import Index
+    from helpers import assert_ranking_matches
+
+    torch, E, Q = world["torch"], world["E"], world["Q"]
+    k = 10
+    src = (np.arange(N, dtype=np.int64) % 300).astype(np.uint16)
+    allow = np.zeros(300, np.uint8)
+    allow[45:] = 1                                            # ~15 % of the rows drop out
+    keep = torch.from_numpy(allow[src].astype(bool)).to(E.device)
+    scores = Q @ E.T
+    scores[:, ~keep] = float("-inf")
+    ref = scores.topk(k, dim=1)
+    ri, rv = ref.indices.cpu().numpy(), ref.values.cpu().numpy()
+    qh = Q.cpu().numpy()
+    torch.cuda.synchronize()
+    with Index(0) as idx:
+        idx.dense_load((E.data_ptr(), N, D), source_id=src)
+        for mode in ("f32", "bf16x3"):
+            idx.set_batched_precision(mode)
+            d, s, c = idx.dense_search(qh, k, allow)
+            assert np.all(c == k)
+            assert np.all(allow[src[d]] == 1), mode
+            for i in range(len(qh)):
+                assert_ranking_matches(ri[i], rv[i], d[i], s[i], 1e-4, None, f"{mode} query {i}")
