@@ -25,6 +25,7 @@ for i, t in enumerate(terms):
     T[i, : len(t)] = torch.from_numpy(np.asarray(t, np.int32)).to(dev)
 nt = [len(t) for t in terms]
 out = torch.zeros((64, 25, 2), dtype=torch.int64, device=dev)
+torch.cuda.synchronize()
 lib = nat.load_library()
 lib.anrag_debug_k3_stamps.argtypes = [C.c_void_p, C.c_int]
 n_parts = (n + 4095) // 4096 if n >= 256 * 4096 else None

@@ -20,6 +20,7 @@ idx.set_batched_precision(prec)
 lib = nat.load_library()
 out = torch.zeros((nq, k, 2), dtype=torch.int64, device=dev)
 flag = torch.zeros(nq, dtype=torch.int32, device=dev)
+torch.cuda.synchronize()  # torch fills on its own stream; the library writes on its streams
 def run():
     nat.check(lib.anrag_dense_search_batch_device(idx.handle, Q.data_ptr(), nq, k, None, out.data_ptr(), flag.data_ptr()))
 run(); idx.sync()

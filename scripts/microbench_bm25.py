@@ -28,6 +28,7 @@ for i, t in enumerate(terms):
     T[i, : len(t)] = torch.from_numpy(np.asarray(t, np.int32)).to(dev)
 nt = [len(t) for t in terms]
 out = torch.zeros((64, 25, 2), dtype=torch.int64, device=dev)
+torch.cuda.synchronize()  # torch fills / uploads on its own stream; the library reads and writes on its streams
 torch.cuda.synchronize()
 lib = nat.load_library()
 alg = np.mean([sum(int(df[t]) for t in tl) * 12 for tl in terms])

@@ -15,6 +15,7 @@ Q, _ = synth.dense_queries(E, 64, 4321)
 torch.cuda.synchronize()
 idx = Index(0); idx.dense_load((E.data_ptr(), n, d))
 out = torch.zeros((64, k, 2), dtype=torch.int64, device=dev)
+torch.cuda.synchronize()
 ref = (Q @ E.T).topk(k, dim=1).indices.cpu().numpy()
 lib = nat.load_library()
 def run(calls):

@@ -14,6 +14,7 @@ E = synth.dense_corpus(1_000_000, d, 1234, dev)
 Q, _ = synth.dense_queries(E, 64, 4321)
 torch.cuda.synchronize()
 out = torch.zeros((64, 10, 2), dtype=torch.int64, device=dev)
+torch.cuda.synchronize()
 lib = nat.load_library()
 res = []
 for rows in (1_000_000, 500_000, 125_000, 100_000):

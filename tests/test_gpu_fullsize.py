@@ -113,6 +113,7 @@ def test_c5_rank_shape_1m_x1024_hybrid():
         ref = (Q @ E.T).topk(k, dim=1)
         out = torch.zeros((2 * k, 2), dtype=torch.int64, device=dev)
         T = torch.full((16,), -1, dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()  # torch fills / copies on ITS stream; the library reads and writes on its own streams
         for qi in range(8):
             q = Q[qi].cpu().numpy()
             doc, score, cnt = idx.dense_search(q, k)
@@ -125,6 +126,7 @@ def test_c5_rank_shape_1m_x1024_hybrid():
                                                               {"d": 5.0, "b": 1.0}, 40)[:10]
             assert ids.tolist() == [i for i, _ in want] and scores.tolist() == [s for _, s in want]
             T[: len(terms[qi])] = torch.from_numpy(np.asarray(terms[qi], np.int32)).to(dev)
+            torch.cuda.synchronize()
             nat.check(lib.anrag_hybrid_candidates_device(idx.handle, Q[qi].data_ptr(), T.data_ptr(), len(terms[qi]), k,
                                                          None, None, out.data_ptr()))
             idx.sync()
@@ -144,6 +146,7 @@ def test_sharded_merge_equals_whole(world):
         b.dense_load((E.data_ptr() + half * D * 4, N - half, D), doc_id_base=half)
         lists = torch.zeros((2, k, 2), dtype=torch.int64, device=E.device)
         out = torch.zeros((k, 2), dtype=torch.int64, device=E.device)
+        torch.cuda.synchronize()  # the zero fills run on torch's stream: over before the library writes the buffers
         for qi in range(4):
             a.dense_search_device(Q[qi].data_ptr(), 1, k, 0, lists[0].data_ptr())
             b.dense_search_device(Q[qi].data_ptr(), 1, k, 0, lists[1].data_ptr())

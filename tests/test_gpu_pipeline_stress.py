@@ -66,6 +66,7 @@ def test_mixed_bursts_match_serial():
                     assert oc[i, 25:, 1].tolist() == bm25_ref[i].tolist(), (rounds, i)
         # plain dense bursts after the pipeline has been busy
         out_d = torch.zeros((nq, 10, 2), dtype=torch.int64, device=dev)
+        torch.cuda.synchronize()
         idx.dense_search_device(Q.data_ptr(), nq, 10, 0, out_d.data_ptr())
         idx.sync()
         od = out_d.cpu().numpy()

@@ -58,6 +58,7 @@ def test_sharded_pipeline_world1_rccl():
             t = bi.term_ids(toks)
             T[i, : len(t)] = torch.from_numpy(t).to(device)
             nt.append(len(t))
+        torch.cuda.synchronize()  # the uploads ran on torch's stream; the engine reads Q / T on its own streams
         # group=3: the local legs of an exchange group go to the library in one call (grouped scan launches, a
         # partial group at drain); group=1: one call per query
         allow = np.array([1, 0, 1, 1, 0], dtype=np.uint8)
