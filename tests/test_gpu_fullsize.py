@@ -247,3 +247,42 @@ def test_c4_with_a_source_filter_at_full_size(world):
             assert np.all(allow[src[d]] == 1), mode
             for i in range(len(qh)):
                 assert_ranking_matches(ri[i], rv[i], d[i], s[i], 1e-4, None, f"{mode} query {i}")
+
+
+def test_corpus_past_2_to_31_elements():
+    """3M x 768 = 2.3e9 elements, 9.2 GB: every offset past 2^31 elements / 2^32 bytes (a C5 shard at 1M x 1024 stays just
+    below both).  Queries planted next to the LAST rows; K1, both K2 modes, the score-array form, the fp64 entry point and
+    anrag_dense_scores against torch."""
+    import torch
+    from anrag import synth
+    from anrag.index import Index
+
+    dev = torch.device("cuda", 0)
+    n, d, k = 3_000_000, 768, 10
+    E = synth.dense_corpus(n, d, 5, dev)
+    Q, _ = synth.dense_queries(E, 40, 6)
+    hi_rows = torch.tensor([n - 1, n - 7, 2_900_000, 2_800_001], device=dev)
+    Q[:4] = E[hi_rows] + 0.02 * torch.randn((4, d), device=dev)
+    Q[:4] /= Q[:4].norm(dim=1, keepdim=True)
+    tops = [(Q[i:i + 8] @ E.T).topk(k, dim=1) for i in range(0, 40, 8)]
+    ri = torch.cat([t.indices for t in tops]).cpu().numpy()
+    rv = torch.cat([t.values for t in tops]).cpu().numpy()
+    full0 = (Q[0] @ E.T).cpu().numpy()
+    qh = Q.cpu().numpy()
+    torch.cuda.synchronize()
+    with Index(0) as idx:
+        idx.dense_load((E.data_ptr(), n, d))
+        d1, s1, _ = idx.dense_search(qh[:6], k)                      # K1
+        assert np.array_equal(d1, ri[:6]) and np.max(np.abs(s1 - rv[:6])) <= 1e-4
+        assert d1[:4, 0].tolist() == hi_rows.cpu().tolist()
+        for mode in ("f32", "bf16x3"):                                # K2
+            idx.set_batched_precision(mode)
+            d2, s2, _ = idx.dense_search(qh, k)
+            assert np.mean(d2 == ri) > 0.995 and np.max(np.abs(s2 - rv)) <= 1e-4, mode
+            assert d2[:4, 0].tolist() == hi_rows.cpu().tolist()
+        idx.set_batched_precision("f32")
+        d3, _, _ = idx.dense_search(qh[0], 200)                      # score array + sort
+        assert d3[0, :k].tolist() == ri[0].tolist()
+        d4, _, _ = idx.dense_search_f64(qh[0].astype(np.float64), k)  # fp64 entry point
+        assert d4.tolist() == ri[0].tolist()
+        assert np.max(np.abs(idx.dense_scores(qh[0]) - full0)) <= 1e-5
