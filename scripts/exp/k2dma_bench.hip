@@ -1,10 +1,18 @@
 // Standalone experiment (not part of the library): where does the time of the split-precision K2 full pass go?
-// The 4-stage LDS-DMA kernel of round 2 with the copies and / or the MFMAs switched off.
-// RESULT (MI355X, 1M x 768 as images): the copies alone -- 16 KB of corpus images from HBM + 16 KB of query images from
-// L2 per step and CU -- take 0.68 us per step = 5.85 TB/s of corpus (4 or 8 copying waves alike; query copies alone
-// 0.16 us): LDS-DMA staging is NOT what holds the kernel at 1.8 us per step.  The variants with MFMAs spill in this
-// stand-alone build (132-156 VGPRs, unlike the library build of the same code): their times are not usable.
-//   hipcc -O3 --offload-arch=gfx950 scripts/exp/k2dma_bench.hip -o scripts/exp/k2dma_bench && scripts/exp/k2dma_bench
+// The LDS-DMA ring of dense_batched_split_dma_kernel (four 32 KB stages, k-steps of 16, three in flight) with the copies,
+// the fragment reads and the MFMAs switched on and off, with and without ping-pong waves, and with in-kernel clocks
+// (s_memtime = shader clock, s_memrealtime = 100 MHz) so that every variant reports the clock it actually ran at.
+// 200 warm-up + 200 timed back-to-back launches per variant (the clock needs tens of launches to settle);
+// K2_REALISTIC=1 fills the images with N(0, 1/768) values split into bf16 hi / lo (the power the matrix pipes draw
+// depends on the operand bits).
+// RESULTS (MI355X, 1M x 768 as images, realistic operands; DESIGN.md section 3 has the table):
+//   copies only 0.52 ms at 2.39 GHz (5.9 TB/s); MFMAs only 0.66 ms at 1.81 GHz with the pipe 100 % busy -- the matrix
+//   pipes alone pull the board to its power limit; ping-pong without copies 0.70 ms; every FULL variant (no ping-pong,
+//   ping-pong with the copies at phase start / in the read phase / spread over 4 or 8 waves, 2 or 3 stages in flight)
+//   0.96-0.99 ms at 1.55-1.63 GHz: a schedule that removes stalls is answered by a lower clock.
+//   The issue of an HBM-bound global_load_lds blocks its wave for 400-800 cycles (the stamps of the ping-pong variants).
+//   The compiler moves MFMAs (register-only) across an `s_barrier` asm: sched_barrier(0) on both sides is needed.
+//   hipcc -O3 --offload-arch=gfx950 scripts/exp/k2dma_bench.hip -o scripts/exp/k2dma_bench && K2_REALISTIC=1 scripts/exp/k2dma_bench
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
