@@ -8,9 +8,10 @@
 // MFMA-bound (the 3.07 GB corpus is read once per pass: 1.2 TB/s at peak rate).
 //
 // Exact top-k without materialising the Q x N score matrix (1 GB at 256 x 1M):
-//   1. SAMPLE pass   the same GEMM over every (N/S)-th corpus row -> scores[Q][S]; a wave per query
-//                    takes the k-th best allowed sampled score tau_q.  The k-th best over ALL rows is
-//                    >= the k-th best over a subset, so tau_q is a valid lower bound.
+//   1. SAMPLE pass   the same GEMM over every (N/S)-th corpus row; each lane keeps the best two allowed scores of
+//                    its rows per query column (dense_batched_common.hpp), a workgroup per query takes the k-th
+//                    best of those, tau_q.  The k-th best over ALL rows is >= the k-th best over a subset, so
+//                    tau_q is a valid lower bound.
 //   2. FILTER pass   the full GEMM; the epilogue appends (score,row) with score >= tau_q to the
 //                    query's candidate list (one global atomic per survivor; ~N*k/S survivors per query).
 //   3. SELECT        a wave per query ranks its survivors (score desc, row asc) -> k records.
@@ -313,7 +314,7 @@ bool batched_path_applies(const anrag_index *idx, int32_t n_queries, int32_t k) 
            idx->n_rows < 0xffffffffLL;  // survivor records carry 32-bit rows
 }
 
-static int ensure_batched_workspace(anrag_index *idx, int64_t n_sample) {
+static int ensure_batched_workspace(anrag_index *idx, int64_t n_sample /* floats per query */) {
     if (!idx->d_bq) {
         ANRAG_HIP(hipMalloc(reinterpret_cast<void **>(&idx->d_bq), (size_t)kBQ * idx->dim * sizeof(float)));
         ANRAG_HIP(hipMalloc(reinterpret_cast<void **>(&idx->d_btau), kBQ * sizeof(float)));
@@ -396,7 +397,8 @@ static int batched_passes(anrag_index *idx, hipStream_t st, int32_t nq, int32_t 
         dense_batched_kernel<128, true, false><<<batched_grid<128>(idx, n_sample, sq), GeoS::kThreads, GeoS::kLdsBytes, st>>>(
             idx->d_emb, idx->d_bq, sq, n, dim, nq, n_sample, stride, nullptr, idx->d_bsample, nullptr, nullptr, 0,
             nullptr, nullptr);
-    batched_threshold_kernel<<<nq, kThrWaves * 64, 0, st>>>(idx->d_bsample, n_sample, k, idx->d_btau, idx->d_bcnt);
+    batched_threshold_kernel<<<nq, kThrWaves * 64, 0, st>>>(idx->d_bsample, sample_floats_per_query(n_sample, kBM), k,
+                                                             idx->d_btau, idx->d_bcnt);
     if (allow)
         dense_batched_kernel<QW, false, true><<<batched_grid<QW>(idx, n, n_qblocks), Geo::kThreads, Geo::kLdsBytes, st>>>(
             idx->d_emb, idx->d_bq, n_qblocks, n, dim, nq, n, 1, idx->d_btau, nullptr, idx->d_bcnt, cand, kCandCap,
@@ -432,10 +434,8 @@ int launch_dense_batched(anrag_index *idx, hipStream_t st, const float *d_querie
     const int64_t round_rows = (int64_t)idx->n_cus * (idx->batched_split ? 256 : kBM);
     const int64_t filled = (n_sample + round_rows - 1) / round_rows * round_rows;
     if (filled <= n / 8) n_sample = filled;
-    n_sample &= ~(int64_t)3;  // the sampled pass stores four scores at a time
-    if (n_sample < 4) n_sample = n;
     const int64_t stride = n / n_sample;
-    int rc = ensure_batched_workspace(idx, n_sample);
+    int rc = ensure_batched_workspace(idx, sample_floats_per_query(n_sample, idx->batched_split ? 256 : kBM));
     if (rc) return rc;
     // zero-padded query block
     ANRAG_HIP(hipMemsetAsync(idx->d_bq, 0, (size_t)kBQ * dim * sizeof(float), st));

@@ -91,8 +91,8 @@ __device__ __noinline__ int tile_survivors(f32x16 v, uint32_t row0, int q, float
 }
 
 // Epilogue of one (64*TI) x QW tile held as TI x 2 MFMA accumulators per wave: D[corpus row][query], lane = query
-// column, 16 rows per register set (32x32 C/D map: row = (r&3) + 8*(r>>2) + 4*(lane>>5)).  SAMPLE: store every
-// score of the sampled rows; otherwise 16 compares per accumulator tile, and the per-score path above only for a tile
+// column, 16 rows per register set (32x32 C/D map: row = (r&3) + 8*(r>>2) + 4*(lane>>5)).  SAMPLE: store each lane's
+// two best scores per query column; otherwise 16 compares per accumulator tile, and the per-score path above only for a tile
 // that holds a survivor (my_tau must be +huge for padding queries).  Zeroes the accumulators.
 template <bool SAMPLE, bool FILTER, int TI = 2, int ENTRIES = 448>
 __device__ __forceinline__ void batched_tile_epilogue(f32x16 (&acc)[TI][2], int64_t tile, int rw, int qw, int qbase,
@@ -103,31 +103,45 @@ __device__ __forceinline__ void batched_tile_epilogue(f32x16 (&acc)[TI][2], int6
                                                       const uint32_t *__restrict__ allow_bits, unsigned char *slice,
                                                       int &fill) {
     // a workgroup tile is 2 (row halves) x TI x 32 corpus rows: TI = 2 -> 128 rows (kBM), TI = 4 -> 256 rows
-#pragma unroll
-    for (int ti = 0; ti < TI; ++ti)
+    if constexpr (SAMPLE) {
+        // A lane holds TI x 16 sampled rows of each of its two query columns: it keeps the BEST TWO of them and writes
+        // those -- sample_scores[query][slot][2], slot = (tile, row half, lane half).  The threshold is the k-th best
+        // of a query's slots: still the score of a real row with k - 1 real rows ahead of it, i.e. a lower bound on the
+        // k-th best of the corpus; and hardly lower than the k-th best of ALL sampled rows (it differs only when three
+        // of the k best sampled rows share one lane's 16 TI rows).  Writing every score (16.7M four-byte stores scattered
+        // over 256 query rows, then read back by the threshold kernel) was the larger part of the pre-pass.
+        const int64_t n_tiles = (n_work + 2 * TI * 32 - 1) / (2 * TI * 32);
 #pragma unroll
         for (int tj = 0; tj < 2; ++tj) {
-            const int q = qbase + qw * 64 + tj * 32 + l31;
-            const int64_t row0 = tile * (2 * TI * 32) + rw * (TI * 32) + ti * 32 + 4 * lh;
-            if constexpr (SAMPLE) {
-                // registers 4g .. 4g+3 are four consecutive rows: one 16-byte store each (n_work is a multiple of 4, so
-                // a group is inside or outside as a whole)
+            float b1 = neg_inf<float>(), b2 = neg_inf<float>();
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int64_t wr = row0 + 8 * g;
-                    f32x4 o;
+            for (int ti = 0; ti < TI; ++ti)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        float s = acc[ti][tj][4 * g + j];
-                        if (s != s) s = __builtin_huge_valf();  // NaN ranks first, as in K1 (and in numpy)
-                        if constexpr (FILTER) {
-                            if (wr < n_work && !source_ok(allow_bits, src[(wr + j) * stride])) s = neg_inf<float>();
-                        }
-                        o[j] = s;
+                for (int r = 0; r < 16; ++r) {
+                    const int64_t wr = tile * (2 * TI * 32) + rw * (TI * 32) + ti * 32 + 4 * lh + (r & 3) + 8 * (r >> 2);
+                    float s = acc[ti][tj][r];
+                    if (s != s) s = __builtin_huge_valf();  // NaN ranks first, as in K1 (and in numpy)
+                    bool ok = wr < n_work;
+                    if constexpr (FILTER) {
+                        if (ok) ok = source_ok(allow_bits, src[wr * stride]);
                     }
-                    if (wr < n_work) *reinterpret_cast<f32x4 *>(sample_scores + (int64_t)q * n_work + wr) = o;
+                    if (!ok) s = neg_inf<float>();
+                    const float lo = s < b1 ? s : b1;  // the smaller of (s, b1) competes for second place
+                    b1 = s < b1 ? b1 : s;
+                    b2 = lo < b2 ? b2 : lo;
                 }
-            } else {
+            const int q = qbase + qw * 64 + tj * 32 + l31;
+            const int64_t slot = (tile * 2 + rw) * 2 + lh;
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            *reinterpret_cast<f32x2 *>(sample_scores + ((int64_t)q * n_tiles * 4 + slot) * 2) = f32x2{b1, b2};
+        }
+    } else {
+#pragma unroll
+        for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+            for (int tj = 0; tj < 2; ++tj) {
+                const int q = qbase + qw * 64 + tj * 32 + l31;
+                const int64_t row0 = tile * (2 * TI * 32) + rw * (TI * 32) + ti * 32 + 4 * lh;
                 bool hit = false;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) hit |= !(acc[ti][tj][r] < my_tau[tj]);
@@ -135,9 +149,18 @@ __device__ __forceinline__ void batched_tile_epilogue(f32x16 (&acc)[TI][2], int6
                     fill = tile_survivors<FILTER, ENTRIES>(acc[ti][tj], (uint32_t)row0, q < nq ? q : -1, my_tau[tj],
                                                            (uint32_t)n_work, slice, fill, cnt, cand, src, allow_bits);
             }
+    }
+#pragma unroll
+    for (int ti = 0; ti < TI; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[ti][tj][r] = 0.f;
-        }
+}
+
+// floats per query the sampled pass of tile height `tile_rows` writes for n_sample rows (two per slot, above)
+inline int64_t sample_floats_per_query(int64_t n_sample, int tile_rows) {
+    return (n_sample + tile_rows - 1) / tile_rows * 8;
 }
 
 // dense_batched_split.hip

@@ -463,7 +463,8 @@ int batched_passes_split(anrag_index *idx, hipStream_t st, int32_t nq, int32_t k
     else
         dense_batched_split_kernel<true, false><<<grid_for(n_sample), kSplitThreads, kSplitLdsBytes, st>>>(
             idx->d_emb, qh, ql, dim, nq, n_sample, stride, nullptr, idx->d_bsample, nullptr, nullptr, 0, nullptr, nullptr);
-    batched_threshold_kernel<<<nq, kThrWaves * 64, 0, st>>>(idx->d_bsample, n_sample, k, idx->d_btau, idx->d_bcnt);
+    batched_threshold_kernel<<<nq, kThrWaves * 64, 0, st>>>(idx->d_bsample, sample_floats_per_query(n_sample, kSM), k,
+                                                             idx->d_btau, idx->d_bcnt);
     const unsigned char *e_img = static_cast<const unsigned char *>(idx->d_split_img);
     const unsigned char *q_img = static_cast<const unsigned char *>(idx->d_bq_img);
     if (allow)
