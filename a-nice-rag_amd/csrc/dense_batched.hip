@@ -53,7 +53,7 @@ __global__ __launch_bounds__(BatchGeom<QW>::kThreads, 2) void dense_batched_kern
     const float *__restrict__ emb, const float *__restrict__ queries /* [kBQ][dim], zero padded */, int32_t n_qblocks,
     int64_t n_rows /* corpus rows */, int32_t dim, int32_t nq, int64_t n_work /* rows this pass visits */,
     int64_t stride /* SAMPLE: corpus row = work row * stride */, const float *__restrict__ tau,
-    float *__restrict__ sample_scores /* [kBQ][n_work] */, int32_t *__restrict__ cnt, Cand32 *__restrict__ cand,
+    float *__restrict__ sample_scores /* [kBQ][tiles * 4 slots][2] */, int32_t *__restrict__ cnt, Cand32 *__restrict__ cand,
     int32_t cap, const uint16_t *__restrict__ src, const uint32_t *__restrict__ allow_bits) {
     using Geo = BatchGeom<QW>;
     constexpr int kBatchThreads = Geo::kThreads, kBufFloats = Geo::kBufFloats, kBQW = QW;
