@@ -212,8 +212,8 @@ __global__ __launch_bounds__(kSplitThreads, 2) void dense_batched_split_kernel(
 }
 
 // ------------------------------------------------------------------ the full pass: LDS-DMA staging, ping-pong waves
-// The full pass streams the whole corpus once, so it gets its own kernel (the sampled pass above reads 1/16 of the
-// rows, strided, and stays on the register-staged kernel).  What is different:
+// The full pass streams the whole corpus once, so it gets its own kernel (the sampled pass above reads a few per cent
+// of the rows, strided, and stays on the register-staged kernel).  What is different:
 //
 //  * The corpus is kept a second time as READY-TO-COPY IMAGES (built on the first split-precision pass after a load,
 //    +4 bytes per element of HBM): for every tile of 256 rows and every k-step of 16, an 8 KB hi image and an 8 KB lo
@@ -225,9 +225,9 @@ __global__ __launch_bounds__(kSplitThreads, 2) void dense_batched_split_kernel(
 //    barrier.  The matrix pipe always has one wave feeding it and no wave needs a second fragment set (128
 //    accumulator + 48 fragment registers).  scripts/exp/k2dma_bench.hip holds the stand-alone measurements: without
 //    copies this loop is within 4 % of an MFMA-only loop; with them the kernel sits on the board's POWER limit (the
-//    shader clock falls to ~1.65 GHz: every schedule variant lands on the same 0.92 ms per 1M x 768 pass).
+//    shader clock falls to ~1.6 GHz: every schedule variant lands on the same 0.96 ms per 1M x 768 pass).
 //  * The tile epilogue looks at 16 scores with 16 compares and takes the per-score path only for an accumulator
-//    tile that holds a survivor (or a NaN); survivors go through a per-wave LDS buffer (below).
+//    tile that holds a survivor (or a NaN); survivors go through a per-wave LDS slice (dense_batched_common.hpp).
 constexpr int kDK = 16;                         // k per stage
 constexpr int kDImg = kSM * kDK * 2;            // one image: 256 rows x 16 bf16 = 8 KB
 constexpr int kDStage = 4 * kDImg;              // corpus hi, corpus lo, query hi, query lo
