@@ -422,16 +422,19 @@ int launch_dense_batched(anrag_index *idx, hipStream_t st, const float *d_querie
     // survivors per query.  The sampled pass costs ~1 ns per row (beyond the ~64k rows that merely fill the CUs), a
     // survivor ~0.8 ns x 256 queries: the sum is smallest near S = sqrt(128 N k) (36k rows, ~280 survivors per query at
     // 1M x k=10; a fixed N*k/S = cap/4 = 2,048 made the survivors 6 % of the f32 pass and 30 % of the split one).  The
-    // f32 pass costs ~3 ns per row and its survivors ~0.4 ns: sqrt(32 N k).
+    // f32 pass costs ~3 ns per row and its survivors less since they go through LDS: sqrt(24 N k) (one workgroup per CU
+    // and query block at 1M x k=10: 16,384 rows, 3.12 -> 3.09 ms per pass against two per CU).
     // Never fewer rows than keep the expected survivors under cap/4.
-    int64_t n_sample = (int64_t)__builtin_sqrt((idx->batched_split ? 128.0 : 32.0) * (double)n * (double)k);
+    int64_t n_sample = (int64_t)__builtin_sqrt((idx->batched_split ? 128.0 : 24.0) * (double)n * (double)k);
     const int64_t floor_rows = (4 * n * (int64_t)k + kCandCap - 1) / kCandCap;
     if (n_sample < floor_rows) n_sample = floor_rows;
     if (n_sample < 4096) n_sample = 4096;
     if (n_sample > n) n_sample = n;
     // a round of tiles (one per CU) costs the same whether the tiles are all there or not: fill the round, as long as the
     // sample stays a small part of the corpus
-    const int64_t round_rows = (int64_t)idx->n_cus * (idx->batched_split ? 256 : kBM);
+    // (f32: the sampled pass runs the 128-query geometry, two workgroups per CU when there are more than 128 queries --
+    // a "round" is then one workgroup per CU per query block = half as many rows)
+    const int64_t round_rows = idx->batched_split ? (int64_t)idx->n_cus * 256 : (int64_t)idx->n_cus * kBM / (nq > 128 ? 2 : 1);
     const int64_t filled = (n_sample + round_rows - 1) / round_rows * round_rows;
     if (filled <= n / 8) n_sample = filled;
     const int64_t stride = n / n_sample;
