@@ -91,12 +91,12 @@ __device__ __noinline__ int tile_survivors(f32x16 v, uint32_t row0, int q, float
 }
 
 // Epilogue of one (64*TI) x QW tile held as TI x 2 MFMA accumulators per wave: D[corpus row][query], lane = query
-// column, 16 rows per register set (32x32 C/D map: row = (r&3) + 8*(r>>2) + 4*(lane>>5)).  SAMPLE: store each lane's
+// column (a wave owns TJ x 32 of them), 16 rows per register set (32x32 C/D map: row = (r&3) + 8*(r>>2) + 4*(lane>>5)).  SAMPLE: store each lane's
 // two best scores per query column; otherwise 16 compares per accumulator tile, and the per-score path above only for a tile
 // that holds a survivor (my_tau must be +huge for padding queries).  Zeroes the accumulators.
-template <bool SAMPLE, bool FILTER, int TI = 2, int ENTRIES = 448>
-__device__ __forceinline__ void batched_tile_epilogue(f32x16 (&acc)[TI][2], int64_t tile, int rw, int qw, int qbase,
-                                                      int l31, int lh, const float (&my_tau)[2], int64_t n_work,
+template <bool SAMPLE, bool FILTER, int TI = 2, int ENTRIES = 448, int TJ = 2>
+__device__ __forceinline__ void batched_tile_epilogue(f32x16 (&acc)[TI][TJ], int64_t tile, int rw, int qw, int qbase,
+                                                      int l31, int lh, const float (&my_tau)[TJ], int64_t n_work,
                                                       int64_t stride, int32_t nq, float *__restrict__ sample_scores,
                                                       int32_t *__restrict__ cnt, Cand32 *__restrict__ cand, int32_t cap,
                                                       const uint16_t *__restrict__ src,
@@ -112,7 +112,7 @@ __device__ __forceinline__ void batched_tile_epilogue(f32x16 (&acc)[TI][2], int6
         // over 256 query rows, then read back by the threshold kernel) was the larger part of the pre-pass.
         const int64_t n_tiles = (n_work + 2 * TI * 32 - 1) / (2 * TI * 32);
 #pragma unroll
-        for (int tj = 0; tj < 2; ++tj) {
+        for (int tj = 0; tj < TJ; ++tj) {
             float b1 = neg_inf<float>(), b2 = neg_inf<float>();
 #pragma unroll
             for (int ti = 0; ti < TI; ++ti)
@@ -130,7 +130,7 @@ __device__ __forceinline__ void batched_tile_epilogue(f32x16 (&acc)[TI][2], int6
                     b1 = s < b1 ? b1 : s;
                     b2 = lo < b2 ? b2 : lo;
                 }
-            const int q = qbase + qw * 64 + tj * 32 + l31;
+            const int q = qbase + qw * (TJ * 32) + tj * 32 + l31;
             const int64_t slot = (tile * 2 + rw) * 2 + lh;
             typedef float f32x2 __attribute__((ext_vector_type(2)));
             *reinterpret_cast<f32x2 *>(sample_scores + ((int64_t)q * n_tiles * 4 + slot) * 2) = f32x2{b1, b2};
@@ -139,8 +139,8 @@ __device__ __forceinline__ void batched_tile_epilogue(f32x16 (&acc)[TI][2], int6
 #pragma unroll
         for (int ti = 0; ti < TI; ++ti)
 #pragma unroll
-            for (int tj = 0; tj < 2; ++tj) {
-                const int q = qbase + qw * 64 + tj * 32 + l31;
+            for (int tj = 0; tj < TJ; ++tj) {
+                const int q = qbase + qw * (TJ * 32) + tj * 32 + l31;
                 const int64_t row0 = tile * (2 * TI * 32) + rw * (TI * 32) + ti * 32 + 4 * lh;
                 bool hit = false;
 #pragma unroll
@@ -153,7 +153,7 @@ __device__ __forceinline__ void batched_tile_epilogue(f32x16 (&acc)[TI][2], int6
 #pragma unroll
     for (int ti = 0; ti < TI; ++ti)
 #pragma unroll
-        for (int tj = 0; tj < 2; ++tj)
+        for (int tj = 0; tj < TJ; ++tj)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[ti][tj][r] = 0.f;
 }

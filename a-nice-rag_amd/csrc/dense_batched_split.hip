@@ -266,7 +266,9 @@ constexpr int kSurvEntries = 448;               // survivors per wave slice: 448
 constexpr int kSurvSlice = 4096;
 constexpr int kDmaLdsTotal = kDmaLdsBytes + 8 * kSurvSlice;  // 160 KB: all of a CU's LDS
 
-template <bool FILTER>
+// TJ = accumulator tiles per wave along the queries: 2 = all 256 queries of the block, 1 = the first 128 (a pass of
+// <= 128 queries then does half the matrix work and copies half the query images instead of multiplying padding).
+template <bool FILTER, int TJ>
 __global__ __launch_bounds__(kSplitThreads, 2) void dense_batched_split_dma_kernel(
     const unsigned char *__restrict__ e_img, const unsigned char *__restrict__ q_img, int32_t ksteps, int32_t nq,
     int64_t n_work, const float *__restrict__ tau, int32_t *__restrict__ cnt, Cand32 *__restrict__ cand, int32_t cap,
@@ -281,10 +283,10 @@ __global__ __launch_bounds__(kSplitThreads, 2) void dense_batched_split_dma_kern
     const int64_t total = my_tiles * ksteps;
     if (total == 0) return;
 
-    float my_tau[2];  // padding queries (zero rows of the block) never keep a score
+    float my_tau[TJ];  // padding queries (zero rows of the block) never keep a score
 #pragma unroll
-    for (int tj = 0; tj < 2; ++tj) {
-        const int q = qw * 64 + tj * 32 + l31;
+    for (int tj = 0; tj < TJ; ++tj) {
+        const int q = qw * (TJ * 32) + tj * 32 + l31;
         my_tau[tj] = q < nq ? tau[q] : 3.0e38f;
     }
     int surv_fill = 0;  // wave-uniform: entries in this wave's survivor slice
@@ -296,30 +298,42 @@ __global__ __launch_bounds__(kSplitThreads, 2) void dense_batched_split_dma_kern
     // counted vmcnt waits.
     int64_t ld_tile = first_tile;
     int ld_ks = 0;
+    // per stage a corpus wave issues 4 instructions of 1 KB; a query wave 4 (TJ = 2: a quarter of the 16 KB of query
+    // images) or 2 (TJ = 1: rows 0..127 are the first half of each image; waves 4, 5 take the hi image's, 6, 7 the lo's)
+    constexpr int QI = 2 * TJ;
     auto issue_stage = [&](int slot) {
+        const int y = wave - 4;
+        const int q_off = TJ == 2 ? y * 4096 : (y >> 1) * kDImg + (y & 1) * 2048;
         const unsigned char *g = wave < 4 ? e_img + (ld_tile * ksteps + ld_ks) * (int64_t)(2 * kDImg) + wave * 4096
-                                          : q_img + (int64_t)ld_ks * (2 * kDImg) + (wave - 4) * 4096;
-        unsigned char *d = lds + slot * kDStage + (wave < 4 ? wave * 4096 : 2 * kDImg + (wave - 4) * 4096);
+                                          : q_img + (int64_t)ld_ks * (2 * kDImg) + q_off;
+        unsigned char *d = lds + slot * kDStage + (wave < 4 ? wave * 4096 : 2 * kDImg + q_off);
+        if (wave < 4) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            __builtin_amdgcn_global_load_lds(g + i * 1024 + lane * 16,
-                                             (__attribute__((address_space(3))) void *)(d + i * 1024), 16, 0, 0);
+            for (int i = 0; i < 4; ++i)
+                __builtin_amdgcn_global_load_lds(g + i * 1024 + lane * 16,
+                                                 (__attribute__((address_space(3))) void *)(d + i * 1024), 16, 0, 0);
+        } else {
+#pragma unroll
+            for (int i = 0; i < QI; ++i)
+                __builtin_amdgcn_global_load_lds(g + i * 1024 + lane * 16,
+                                                 (__attribute__((address_space(3))) void *)(d + i * 1024), 16, 0, 0);
+        }
         if (++ld_ks == ksteps) {
             ld_ks = 0;
             if (ld_tile + tile_step < n_tiles) ld_tile += tile_step;
         }
     };
 
-    f32x16 acc[4][2];
+    f32x16 acc[4][TJ];
 #pragma unroll
     for (int ti = 0; ti < 4; ++ti)
 #pragma unroll
-        for (int tj = 0; tj < 2; ++tj)
+        for (int tj = 0; tj < TJ; ++tj)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[ti][tj][r] = 0.f;
 
     struct Frags {
-        bf16x8 ah[4], al[4], bh[2], bl[2];
+        bf16x8 ah[4], al[4], bh[TJ], bl[TJ];
     };
     auto read_frags = [&](int slot, Frags &f) {
         const unsigned char *base = lds + slot * kDStage;
@@ -330,8 +344,8 @@ __global__ __launch_bounds__(kSplitThreads, 2) void dense_batched_split_dma_kern
             f.al[t] = *reinterpret_cast<const bf16x8 *>(base + kDImg + off);
         }
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const int off = dswz(qw * 64 + t * 32 + l31, lh);
+        for (int t = 0; t < TJ; ++t) {
+            const int off = dswz(qw * (TJ * 32) + t * 32 + l31, lh);
             f.bh[t] = *reinterpret_cast<const bf16x8 *>(base + 2 * kDImg + off);
             f.bl[t] = *reinterpret_cast<const bf16x8 *>(base + 3 * kDImg + off);
         }
@@ -341,17 +355,17 @@ __global__ __launch_bounds__(kSplitThreads, 2) void dense_batched_split_dma_kern
 #pragma unroll
         for (int ti = 0; ti < 4; ++ti)
 #pragma unroll
-            for (int tj = 0; tj < 2; ++tj)
+            for (int tj = 0; tj < TJ; ++tj)
                 acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.al[ti], f.bh[tj], acc[ti][tj], 0, 0, 0);
 #pragma unroll
         for (int ti = 0; ti < 4; ++ti)
 #pragma unroll
-            for (int tj = 0; tj < 2; ++tj)
+            for (int tj = 0; tj < TJ; ++tj)
                 acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[ti], f.bl[tj], acc[ti][tj], 0, 0, 0);
 #pragma unroll
         for (int ti = 0; ti < 4; ++ti)
 #pragma unroll
-            for (int tj = 0; tj < 2; ++tj)
+            for (int tj = 0; tj < TJ; ++tj)
                 acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[ti], f.bh[tj], acc[ti][tj], 0, 0, 0);
     };
     int64_t cur_tile = first_tile;
@@ -359,7 +373,7 @@ __global__ __launch_bounds__(kSplitThreads, 2) void dense_batched_split_dma_kern
     auto step_done = [&]() {
         if (++cur_ks < ksteps) return;
         cur_ks = 0;
-        batched_tile_epilogue<false, FILTER, 4, kSurvEntries>(acc, cur_tile, rw, qw, 0, l31, lh, my_tau, n_work, 1, nq,
+        batched_tile_epilogue<false, FILTER, 4, kSurvEntries, TJ>(acc, cur_tile, rw, qw, 0, l31, lh, my_tau, n_work, 1, nq,
                                                               nullptr, cnt, cand, cap, src, allow_bits, slice, surv_fill);
         cur_tile += tile_step;
     };
@@ -374,7 +388,8 @@ __global__ __launch_bounds__(kSplitThreads, 2) void dense_batched_split_dma_kern
     issue_stage(0);
     issue_stage(1);
     issue_stage(2);
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    if (wave < 4 || TJ == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     ANRAG_K2_BAR();
     // Stage c lives in slot c & 3.  Waves 0-3 read it in phase 2c and multiply in phase 2c+1; waves 4-7 read it in
     // phase 2c+1 and multiply in phase 2c+2.  Slot (c+3) & 3 = slot of stage c-1 is free from phase 2c on (its last
@@ -403,7 +418,8 @@ __global__ __launch_bounds__(kSplitThreads, 2) void dense_batched_split_dma_kern
             ANRAG_K2_BAR();
             read_frags((int)(c & 3), f);
             issue_stage((int)((c + 3) & 3));
-            asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+            if constexpr (TJ == 2) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
             ANRAG_K2_BAR();
         }
         mfmas(f);
@@ -424,10 +440,11 @@ int batched_passes_split(anrag_index *idx, hipStream_t st, int32_t nq, int32_t k
                                       hipFuncAttributeMaxDynamicSharedMemorySize, kSplitLdsBytes));
         ANRAG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&dense_batched_split_kernel<true, true>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, kSplitLdsBytes));
-        ANRAG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&dense_batched_split_dma_kernel<false>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, kDmaLdsTotal));
-        ANRAG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&dense_batched_split_dma_kernel<true>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, kDmaLdsTotal));
+        for (const void *f : {reinterpret_cast<const void *>(&dense_batched_split_dma_kernel<false, 2>),
+                              reinterpret_cast<const void *>(&dense_batched_split_dma_kernel<true, 2>),
+                              reinterpret_cast<const void *>(&dense_batched_split_dma_kernel<false, 1>),
+                              reinterpret_cast<const void *>(&dense_batched_split_dma_kernel<true, 1>)})
+            ANRAG_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, kDmaLdsTotal));
         attr_set = true;
     }
     const int64_t n = idx->n_rows;
@@ -467,12 +484,16 @@ int batched_passes_split(anrag_index *idx, hipStream_t st, int32_t nq, int32_t k
                                                              idx->d_btau, idx->d_bcnt);
     const unsigned char *e_img = static_cast<const unsigned char *>(idx->d_split_img);
     const unsigned char *q_img = static_cast<const unsigned char *>(idx->d_bq_img);
-    if (allow)
-        dense_batched_split_dma_kernel<true><<<grid_for(n), kSplitThreads, kDmaLdsTotal, st>>>(
-            e_img, q_img, dim / kDK, nq, n, idx->d_btau, idx->d_bcnt, cand, kCandCap, idx->d_dense_src, allow);
-    else
-        dense_batched_split_dma_kernel<false><<<grid_for(n), kSplitThreads, kDmaLdsTotal, st>>>(
-            e_img, q_img, dim / kDK, nq, n, idx->d_btau, idx->d_bcnt, cand, kCandCap, nullptr, nullptr);
+#define ANRAG_SPLIT_FULL(F, TJ_)                                                                                      \
+    dense_batched_split_dma_kernel<F, TJ_><<<grid_for(n), kSplitThreads, kDmaLdsTotal, st>>>(                          \
+        e_img, q_img, dim / kDK, nq, n, idx->d_btau, idx->d_bcnt, cand, kCandCap, F ? idx->d_dense_src : nullptr,      \
+        F ? allow : nullptr)
+    if (nq <= 128) {
+        if (allow) ANRAG_SPLIT_FULL(true, 1); else ANRAG_SPLIT_FULL(false, 1);
+    } else {
+        if (allow) ANRAG_SPLIT_FULL(true, 2); else ANRAG_SPLIT_FULL(false, 2);
+    }
+#undef ANRAG_SPLIT_FULL
     ANRAG_HIP(hipGetLastError());
     return ANRAG_OK;
 }
