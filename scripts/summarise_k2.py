@@ -5,7 +5,7 @@ import csv, json, os, statistics, subprocess
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC, DST = os.path.join(ROOT, "gpurun_out", "r02k2"), os.path.join(ROOT, "profiles")
 commit = subprocess.run(["git", "rev-parse", "--short", "HEAD"], cwd=ROOT, capture_output=True, text=True).stdout.strip()
-FULL = {"f32": "dense_batched_kernel<256, false, false>", "bf16x3": "dense_batched_split_dma_kernel<false>"}
+FULL = {"f32": "dense_batched_kernel<256, false, false>", "bf16x3": "dense_batched_split_dma_kernel<false, 2>"}
 FLOP = 2.0 * 256 * 1_000_000 * 768
 
 for p in ("f32", "bf16x3"):

@@ -16,7 +16,7 @@ alg = float(line.split("algorithmic ")[1].split(" MB")[0]) * 1e6
 out["K3 bm25_kernel<false,false,1024> (1M docs, 9 terms)"] = {"hbm_bytes": b, "algorithmic_bytes_mean": alg, "ratio": b / alg, "launches": n,
     "note": "algorithmic = sum df(t) x 12 B; the kernel also reads indptr / partition pointers / idf per term and workgroup"}
 for p, kern, alg in (("f32", "dense_batched_kernel<256, false, false>", 1_000_000 * 768 * 4.0),
-                     ("bf16x3", "dense_batched_split_dma_kernel<false>", 3907 * 256 * 768 * 4.0)):
+                     ("bf16x3", "dense_batched_split_dma_kernel<false, 2>", 3907 * 256 * 768 * 4.0)):
     b, n = fetch(os.path.join(SRC, f"pmc_FETCH_SIZE_k2_{p}.csv"), kern)
     out[f"K2 {kern} (256 x 1M x 768)"] = {"hbm_bytes": b, "algorithmic_bytes": alg, "ratio": b / alg, "launches": n,
         "note": "algorithmic = the corpus (images) once; the 768 KB query block is re-read per tile from L2"}
