@@ -35,6 +35,16 @@ class Candidate(C.Structure):
 
 CANDIDATE_DTYPE = np.dtype([("score", "<f8"), ("doc", "<i8")])
 
+LEG_DENSE, LEG_BM25 = 0, 1
+
+
+class RankLeg(C.Structure):
+    """`anrag_rank_leg` (include/anrag.h): one ranked list per query of an `anrag_rank_batch` call."""
+    _fields_ = [("idx", C.c_void_p), ("kind", C.c_int32), ("queries", C.c_void_p), ("term_ids", C.c_void_p),
+                ("term_offsets", C.c_void_p), ("allow_source", C.c_void_p), ("n_sources", C.c_int32),
+                ("doc_of_row", C.c_void_p), ("weight", C.c_double)]
+
+
 _lib: Optional[C.CDLL] = None
 
 _p = C.c_void_p
@@ -78,6 +88,9 @@ _SIGNATURES = {
     "anrag_profile_read": [_p, C.c_int, C.POINTER(_f64), C.POINTER(_i64)],
     "anrag_profile_read_units": [_p, C.c_int, C.POINTER(_i64)],
     "anrag_index_info": [_p, C.POINTER(_i64), C.POINTER(_i32), C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)],
+    "anrag_debug_alloc_calls": [C.POINTER(_i64)],
+    "anrag_rank_batch": [_p, _i32, _i32, _i32, _f64, _i32, _i64, _p, _p, _p, _p, _p],
+    "anrag_rank_caps": [C.POINTER(_i32), C.POINTER(_i32)],
 }
 EXPORTS = tuple(_SIGNATURES) + ("anrag_last_error",)
 

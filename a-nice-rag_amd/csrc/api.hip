@@ -1,6 +1,8 @@
 // C ABI of libanrag.so (include/anrag.h): index lifetime, uploads, query entry points.
 #include <algorithm>
+#include <atomic>
 #include <cmath>
+#include <map>
 #include <cstdlib>
 #include <cstring>
 #include <new>
@@ -17,6 +19,56 @@ void set_error(const char *fmt, ...) {
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
+}
+
+// ------------------------------------------------------------------ counted allocation, per-device attributes
+static std::atomic<int64_t> g_alloc_calls{0};
+int64_t alloc_calls() { return g_alloc_calls.load(); }
+hipError_t counted_malloc(void **p, size_t bytes) {
+    g_alloc_calls.fetch_add(1);
+    return hipMalloc(p, bytes);
+}
+hipError_t counted_free(void *p) {
+    g_alloc_calls.fetch_add(1);
+    return hipFree(p);
+}
+hipError_t counted_host_malloc(void **p, size_t bytes, unsigned flags) {
+    g_alloc_calls.fetch_add(1);
+    return hipHostMalloc(p, bytes, flags);
+}
+hipError_t counted_host_free(void *p) {
+    g_alloc_calls.fetch_add(1);
+    return hipHostFree(p);
+}
+
+int ensure_dynamic_lds(int device, const void *func, int bytes) {
+    static std::mutex mu;
+    static std::map<std::pair<int, const void *>, int> done;
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = done.find({device, func});
+    if (it != done.end() && it->second >= bytes) return ANRAG_OK;
+    ANRAG_HIP(hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));  // on the current device
+    done[{device, func}] = bytes;
+    return ANRAG_OK;
+}
+
+int ensure_pool(anrag_index *idx, DevicePool &pool, int64_t bytes) {
+    if (pool.bytes >= bytes) return ANRAG_OK;
+    if (pool.p) {
+        (void)counted_free(pool.p);
+        idx->hbm_bytes -= pool.bytes;
+    }
+    pool.p = nullptr;
+    pool.bytes = 0;
+    const int64_t want = (bytes + (1 << 20) - 1) / (1 << 20) * (1 << 20);
+    hipError_t e = counted_malloc(reinterpret_cast<void **>(&pool.p), (size_t)want);
+    if (e != hipSuccess) {
+        set_error("hipMalloc(%lld bytes) failed: %s", (long long)want, hipGetErrorString(e));
+        return ANRAG_ERR_NOMEM;
+    }
+    pool.bytes = want;
+    idx->hbm_bytes += want;
+    return ANRAG_OK;
 }
 
 // ------------------------------------------------------------------ profiling
@@ -67,7 +119,7 @@ template <typename T>
 static int dev_alloc(anrag_index *idx, T **p, int64_t count) {
     *p = nullptr;
     if (count <= 0) return ANRAG_OK;
-    hipError_t e = hipMalloc(reinterpret_cast<void **>(p), (size_t)count * sizeof(T));
+    hipError_t e = counted_malloc(reinterpret_cast<void **>(p), (size_t)count * sizeof(T));
     if (e != hipSuccess) {
         set_error("hipMalloc(%lld bytes) failed: %s", (long long)(count * (int64_t)sizeof(T)), hipGetErrorString(e));
         return ANRAG_ERR_NOMEM;
@@ -79,7 +131,7 @@ static int dev_alloc(anrag_index *idx, T **p, int64_t count) {
 template <typename T>
 static void dev_free(anrag_index *idx, T *&p, int64_t count) {
     if (p) {
-        (void)hipFree(p);
+        (void)counted_free(p);
         idx->hbm_bytes -= count * (int64_t)sizeof(T);
         p = nullptr;
     }
@@ -99,7 +151,7 @@ static int ensure_common_workspace(anrag_index *idx) {
     }
     if (!idx->h_pinned) {
         idx->pinned_bytes = 1 << 20;
-        ANRAG_HIP(hipHostMalloc(&idx->h_pinned, idx->pinned_bytes, hipHostMallocDefault));
+        ANRAG_HIP(counted_host_malloc(&idx->h_pinned, idx->pinned_bytes, hipHostMallocDefault));
     }
     return ANRAG_OK;
 }
@@ -128,17 +180,19 @@ static int stage_allow(anrag_index *idx, hipStream_t st, const uint8_t *allow, i
     return ANRAG_OK;
 }
 
-struct DeviceGuard {
-    int prev = -1;
-    bool ok = true;
-    explicit DeviceGuard(int dev) {
-        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
-        if (prev != dev) ok = hipSetDevice(dev) == hipSuccess;
-    }
-    ~DeviceGuard() {
-        if (prev >= 0) (void)hipSetDevice(prev);
-    }
-};
+int sync_all(anrag_index *idx) {
+    ANRAG_HIP(hipStreamSynchronize(idx->primary));
+    ANRAG_HIP(hipStreamSynchronize(idx->secondary));
+    ANRAG_HIP(hipStreamSynchronize(idx->fusion));
+    idx->hyb_outstanding = false;
+    return ANRAG_OK;
+}
+
+// Entry points outside the hybrid pipeline reuse its buffers: let an outstanding pipeline drain first.
+int settle_pipeline(anrag_index *idx) {
+    if (!idx->hyb_outstanding) return ANRAG_OK;
+    return sync_all(idx);
+}
 
 #define ANRAG_ENTER(idx)                                                   \
     ANRAG_REQUIRE((idx) != nullptr, "index handle is NULL");              \
@@ -243,11 +297,14 @@ int anrag_index_destroy(anrag_index *idx) {
                         idx->d_allow_a,       idx->d_allow_b,   idx->d_terms,         idx->d_cand_a,
                         idx->d_cand_out,      idx->d_scores_f64, idx->d_sort_tmp,     idx->d_sort_buf};
         for (void *p : ptrs)
-            if (p) (void)hipFree(p);
+            if (p) (void)counted_free(p);
         free_wrrf_scratch(idx);
         free_batched(idx);
         free_host_slots(idx);
-        if (idx->h_pinned) (void)hipHostFree(idx->h_pinned);
+        if (idx->rank_pool.p) (void)counted_free(idx->rank_pool.p);
+        if (idx->call_pool.p) (void)counted_free(idx->call_pool.p);
+        if (idx->call_pin) (void)counted_host_free(idx->call_pin);
+        if (idx->h_pinned) (void)counted_host_free(idx->h_pinned);
         for (hipEvent_t e : idx->event_pool) (void)hipEventDestroy(e);
         for (int b = 0; b < kPipeSlots; ++b) {
             hipEvent_t evs[] = {idx->ev_scan[b], idx->ev_bm25[b], idx->ev_fused[b]};
@@ -260,20 +317,6 @@ int anrag_index_destroy(anrag_index *idx) {
     }
     delete idx;
     return ANRAG_OK;
-}
-
-static int sync_all(anrag_index *idx) {
-    ANRAG_HIP(hipStreamSynchronize(idx->primary));
-    ANRAG_HIP(hipStreamSynchronize(idx->secondary));
-    ANRAG_HIP(hipStreamSynchronize(idx->fusion));
-    idx->hyb_outstanding = false;
-    return ANRAG_OK;
-}
-
-// Entry points outside the hybrid pipeline reuse its buffers: let an outstanding pipeline drain first.
-static int settle_pipeline(anrag_index *idx) {
-    if (!idx->hyb_outstanding) return ANRAG_OK;
-    return sync_all(idx);
 }
 
 int anrag_index_set_streams(anrag_index *idx, void *primary, void *secondary, void *fusion) {
@@ -404,10 +447,10 @@ static int dense_search_batched_host(anrag_index *idx, hipStream_t st, const flo
     std::vector<int32_t> flag(256);
     anrag_candidate *d_out = nullptr;
     int32_t *d_flag = nullptr;
-    ANRAG_HIP(hipMalloc(reinterpret_cast<void **>(&d_out), (size_t)256 * k * sizeof(anrag_candidate)));
-    hipError_t e = hipMalloc(reinterpret_cast<void **>(&d_flag), 256 * sizeof(int32_t));
+    ANRAG_HIP(counted_malloc(reinterpret_cast<void **>(&d_out), (size_t)256 * k * sizeof(anrag_candidate)));
+    hipError_t e = counted_malloc(reinterpret_cast<void **>(&d_flag), 256 * sizeof(int32_t));
     if (e != hipSuccess) {
-        (void)hipFree(d_out);
+        (void)counted_free(d_out);
         set_error("hipMalloc failed: %s", hipGetErrorString(e));
         return ANRAG_ERR_NOMEM;
     }
@@ -450,8 +493,8 @@ static int dense_search_batched_host(anrag_index *idx, hipStream_t st, const flo
             out_count[q0 + qi] = cnt;
         }
     }
-    (void)hipFree(d_out);
-    (void)hipFree(d_flag);
+    (void)counted_free(d_out);
+    (void)counted_free(d_flag);
     return rc;
 }
 
@@ -593,7 +636,7 @@ int anrag_bm25_scores(anrag_index *idx, const int32_t *term_ids, int32_t n_terms
     int rc;
     if ((rc = stage_terms(idx, st, term_ids, n_terms))) return rc;
     if (!idx->d_scores_f64) {
-        ANRAG_HIP(hipMalloc(reinterpret_cast<void **>(&idx->d_scores_f64), (size_t)idx->n_docs * sizeof(double)));
+        ANRAG_HIP(counted_malloc(reinterpret_cast<void **>(&idx->d_scores_f64), (size_t)idx->n_docs * sizeof(double)));
         idx->hbm_bytes += idx->n_docs * 8;
         idx->bm25_hbm_bytes += idx->n_docs * 8;
     }
@@ -804,8 +847,8 @@ static constexpr size_t kSlotTerms = 4096 * sizeof(int32_t), kSlotAllow = 2048 *
                         kSlotOut = 2 * ANRAG_FUSED_K_MAX * sizeof(anrag_candidate);
 
 static void free_host_slots(anrag_index *idx) {
-    if (idx->host_slots_h) (void)hipHostFree(idx->host_slots_h);
-    if (idx->host_slots_d) (void)hipFree(idx->host_slots_d);
+    if (idx->host_slots_h) (void)counted_host_free(idx->host_slots_h);
+    if (idx->host_slots_d) (void)counted_free(idx->host_slots_d);
     idx->host_slots_h = nullptr;
     idx->host_slots_d = nullptr;
     for (auto &hs : idx->host_slot) {
@@ -830,8 +873,8 @@ static int ensure_host_slots(anrag_index *idx, std::unique_lock<std::mutex> &loc
     // result records | count
     const size_t qbytes = ((size_t)dim * sizeof(float) + 255) / 256 * 256;
     const size_t slot_bytes = qbytes + kSlotTerms + 2 * kSlotAllow + kSlotOut + 256;
-    ANRAG_HIP(hipHostMalloc(reinterpret_cast<void **>(&idx->host_slots_h), slot_bytes * kPipeSlots, hipHostMallocDefault));
-    ANRAG_HIP(hipMalloc(reinterpret_cast<void **>(&idx->host_slots_d), slot_bytes * kPipeSlots));
+    ANRAG_HIP(counted_host_malloc(reinterpret_cast<void **>(&idx->host_slots_h), slot_bytes * kPipeSlots, hipHostMallocDefault));
+    ANRAG_HIP(counted_malloc(reinterpret_cast<void **>(&idx->host_slots_d), slot_bytes * kPipeSlots));
     for (int i = 0; i < kPipeSlots; ++i) {
         anrag_index::HostSlot &hs = idx->host_slot[i];
         hs.h = idx->host_slots_h + (size_t)i * slot_bytes;
@@ -995,15 +1038,15 @@ int anrag_hybrid_search_batch(anrag_index *idx, const float *queries, const int3
     std::vector<int32_t> h_cnt;
     auto body = [&]() -> int {
         if (dense) {
-            ANRAG_HIP(hipMalloc(reinterpret_cast<void **>(&d_q), (size_t)n_queries * idx->dim * sizeof(float)));
+            ANRAG_HIP(counted_malloc(reinterpret_cast<void **>(&d_q), (size_t)n_queries * idx->dim * sizeof(float)));
             ANRAG_HIP(hipMemcpyAsync(d_q, queries, (size_t)n_queries * idx->dim * sizeof(float), hipMemcpyHostToDevice, P));
         }
         if (total_terms > 0) {
-            ANRAG_HIP(hipMalloc(reinterpret_cast<void **>(&d_t), (size_t)total_terms * sizeof(int32_t)));
+            ANRAG_HIP(counted_malloc(reinterpret_cast<void **>(&d_t), (size_t)total_terms * sizeof(int32_t)));
             ANRAG_HIP(hipMemcpyAsync(d_t, term_ids, (size_t)total_terms * sizeof(int32_t), hipMemcpyHostToDevice, P));
         }
-        ANRAG_HIP(hipMalloc(reinterpret_cast<void **>(&d_out), (size_t)n_queries * top_n * sizeof(anrag_candidate)));
-        ANRAG_HIP(hipMalloc(reinterpret_cast<void **>(&d_cnt), (size_t)n_queries * sizeof(int32_t)));
+        ANRAG_HIP(counted_malloc(reinterpret_cast<void **>(&d_out), (size_t)n_queries * top_n * sizeof(anrag_candidate)));
+        ANRAG_HIP(counted_malloc(reinterpret_cast<void **>(&d_cnt), (size_t)n_queries * sizeof(int32_t)));
         ANRAG_HIP(hipMemsetAsync(d_cnt, 0, (size_t)n_queries * sizeof(int32_t), P));
         ANRAG_HIP(hipStreamSynchronize(P));  // the other streams read the staged operands
         for (int32_t q0 = 0; q0 < n_queries; q0 += kScanGroup) {  // one scan launch per group of queries
@@ -1027,7 +1070,7 @@ int anrag_hybrid_search_batch(anrag_index *idx, const float *queries, const int3
     rc = body();
     if (rc) (void)sync_all(idx);  // nothing may still read the operands when they are freed
     for (void *ptr : {(void *)d_q, (void *)d_t, (void *)d_out, (void *)d_cnt})
-        if (ptr) (void)hipFree(ptr);
+        if (ptr) (void)counted_free(ptr);
     if (rc) return rc;
     for (int32_t q = 0; q < n_queries; ++q) {
         const int32_t cnt = std::min(h_cnt[q], top_n);
@@ -1070,13 +1113,13 @@ int anrag_merge_fuse_device(anrag_index *idx, const anrag_candidate *d_lists, in
 int anrag_device_alloc(anrag_index *idx, int64_t bytes, void **out_ptr) {
     ANRAG_ENTER(idx);
     ANRAG_REQUIRE(out_ptr && bytes > 0, "bad arguments");
-    ANRAG_HIP(hipMalloc(out_ptr, (size_t)bytes));
+    ANRAG_HIP(counted_malloc(out_ptr, (size_t)bytes));
     return ANRAG_OK;
 }
 
 int anrag_device_free(anrag_index *idx, void *ptr) {
     ANRAG_ENTER(idx);
-    if (ptr) ANRAG_HIP(hipFree(ptr));
+    if (ptr) ANRAG_HIP(counted_free(ptr));
     return ANRAG_OK;
 }
 
@@ -1144,6 +1187,12 @@ int anrag_profile_read_units(anrag_index *idx, int kernel_id, int64_t *out_units
     int rc = drain_profile(idx);
     if (rc) return rc;
     *out_units = idx->prof_units[kernel_id];
+    return ANRAG_OK;
+}
+
+int anrag_debug_alloc_calls(int64_t *out_calls) {
+    ANRAG_REQUIRE(out_calls != nullptr, "out_calls is NULL");
+    *out_calls = alloc_calls();
     return ANRAG_OK;
 }
 

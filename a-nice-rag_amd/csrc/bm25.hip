@@ -478,7 +478,7 @@ void free_bm25(anrag_index *idx) {
     void *ptrs[] = {idx->d_indptr,   idx->d_post_doc,  idx->d_post_impact, idx->d_idf,
                     idx->d_part_ptr, idx->d_part_slot, idx->d_bm25_src,    idx->d_bm25_doc};
     for (void *p : ptrs)
-        if (p) (void)hipFree(p);
+        if (p) (void)counted_free(p);
     idx->d_indptr = nullptr;
     idx->d_post_doc = nullptr;
     idx->d_post_impact = nullptr;
@@ -487,7 +487,7 @@ void free_bm25(anrag_index *idx) {
     idx->d_part_slot = nullptr;
     idx->d_bm25_src = nullptr;
     idx->d_bm25_doc = nullptr;
-    if (idx->d_scores_f64) (void)hipFree(idx->d_scores_f64);
+    if (idx->d_scores_f64) (void)counted_free(idx->d_scores_f64);
     idx->d_scores_f64 = nullptr;
     idx->hbm_bytes -= idx->bm25_hbm_bytes;
     idx->bm25_hbm_bytes = 0;
@@ -498,7 +498,7 @@ template <typename T>
 static int bm25_alloc(anrag_index *idx, T **p, int64_t count) {
     *p = nullptr;
     if (count <= 0) count = 1;
-    hipError_t e = hipMalloc(reinterpret_cast<void **>(p), (size_t)count * sizeof(T));
+    hipError_t e = counted_malloc(reinterpret_cast<void **>(p), (size_t)count * sizeof(T));
     if (e != hipSuccess) {
         set_error("hipMalloc(%lld bytes) failed: %s", (long long)(count * (int64_t)sizeof(T)), hipGetErrorString(e));
         return ANRAG_ERR_NOMEM;
@@ -563,10 +563,10 @@ int bm25_load(anrag_index *idx, const int64_t *indptr, int64_t n_terms, const in
     // impacts: tf and doc_len are only needed here
     {
         int32_t *d_tf = nullptr, *d_dl = nullptr;
-        ANRAG_HIP(hipMalloc(reinterpret_cast<void **>(&d_tf), (size_t)std::max<int64_t>(n_postings, 1) * 4));
-        hipError_t e = hipMalloc(reinterpret_cast<void **>(&d_dl), (size_t)n_docs * 4);
+        ANRAG_HIP(counted_malloc(reinterpret_cast<void **>(&d_tf), (size_t)std::max<int64_t>(n_postings, 1) * 4));
+        hipError_t e = counted_malloc(reinterpret_cast<void **>(&d_dl), (size_t)n_docs * 4);
         if (e != hipSuccess) {
-            (void)hipFree(d_tf);
+            (void)counted_free(d_tf);
             set_error("hipMalloc failed: %s", hipGetErrorString(e));
             return ANRAG_ERR_NOMEM;
         }
@@ -579,8 +579,8 @@ int bm25_load(anrag_index *idx, const int64_t *indptr, int64_t n_terms, const in
             e = hipGetLastError();
             if (e == hipSuccess) e = hipStreamSynchronize(idx->primary);
         }
-        (void)hipFree(d_tf);
-        (void)hipFree(d_dl);
+        (void)counted_free(d_tf);
+        (void)counted_free(d_dl);
         if (e != hipSuccess) {
             set_error("BM25 impact build failed: %s", hipGetErrorString(e));
             return ANRAG_ERR_HIP;
@@ -599,7 +599,7 @@ int bm25_load(anrag_index *idx, const int64_t *indptr, int64_t n_terms, const in
         if ((rc = bm25_alloc(idx, &idx->d_part_ptr, n_slots * (idx->n_parts + 1)))) return rc;
         if (n_slots > 0) {
             int32_t *d_slot_term = nullptr;
-            ANRAG_HIP(hipMalloc(reinterpret_cast<void **>(&d_slot_term), (size_t)n_slots * 4));
+            ANRAG_HIP(counted_malloc(reinterpret_cast<void **>(&d_slot_term), (size_t)n_slots * 4));
             hipError_t e = hipMemcpy(d_slot_term, slot_term.data(), (size_t)n_slots * 4, hipMemcpyHostToDevice);
             if (e == hipSuccess) {
                 const int64_t total = n_slots * (idx->n_parts + 1);
@@ -609,7 +609,7 @@ int bm25_load(anrag_index *idx, const int64_t *indptr, int64_t n_terms, const in
                 e = hipGetLastError();
                 if (e == hipSuccess) e = hipStreamSynchronize(idx->primary);
             }
-            (void)hipFree(d_slot_term);
+            (void)counted_free(d_slot_term);
             if (e != hipSuccess) {
                 set_error("BM25 partition table build failed: %s", hipGetErrorString(e));
                 return ANRAG_ERR_HIP;
@@ -625,12 +625,12 @@ int bm25_load(anrag_index *idx, const int64_t *indptr, int64_t n_terms, const in
         ANRAG_HIP(copy_in(idx, idx->d_bm25_doc, doc_id, (size_t)n_docs * sizeof(int64_t)));
     }
     // per-partition candidate lists
-    if (idx->d_blk_score_f64) (void)hipFree(idx->d_blk_score_f64);
-    if (idx->d_blk_row_b) (void)hipFree(idx->d_blk_row_b);
+    if (idx->d_blk_score_f64) (void)counted_free(idx->d_blk_score_f64);
+    if (idx->d_blk_row_b) (void)counted_free(idx->d_blk_row_b);
     idx->d_blk_score_f64 = nullptr;
     idx->d_blk_row_b = nullptr;
-    ANRAG_HIP(hipMalloc(reinterpret_cast<void **>(&idx->d_blk_score_f64), (size_t)kPipeSlots * idx->n_parts * kListLen * 8));
-    ANRAG_HIP(hipMalloc(reinterpret_cast<void **>(&idx->d_blk_row_b), (size_t)kPipeSlots * idx->n_parts * kListLen * 4));
+    ANRAG_HIP(counted_malloc(reinterpret_cast<void **>(&idx->d_blk_score_f64), (size_t)kPipeSlots * idx->n_parts * kListLen * 8));
+    ANRAG_HIP(counted_malloc(reinterpret_cast<void **>(&idx->d_blk_row_b), (size_t)kPipeSlots * idx->n_parts * kListLen * 4));
     return ANRAG_OK;
 }
 

@@ -52,6 +52,40 @@ struct ProfSpan {
     int units;  // queries the bracketed launch carried
 };
 
+// Every device / pinned-host allocation and release of the library goes through these four: they count (process-wide)
+// so that a test can assert that a steady-state query loop performs none (anrag_debug_alloc_calls) -- hipMalloc and
+// hipFree synchronise the whole device.
+int64_t alloc_calls();
+hipError_t counted_malloc(void **p, size_t bytes);
+hipError_t counted_free(void *p);
+hipError_t counted_host_malloc(void **p, size_t bytes, unsigned flags);
+hipError_t counted_host_free(void *p);
+template <typename T>
+inline hipError_t counted_malloc(T **p, size_t bytes) { return counted_malloc(reinterpret_cast<void **>(p), bytes); }
+
+// A kernel that asks for more than 64 KB of dynamic LDS needs hipFuncAttributeMaxDynamicSharedMemorySize set -- per
+// DEVICE: remembered per (device, function) under a mutex, so that indexes on several GPUs of one process are
+// independent (include/anrag.h) and concurrent first calls do not race.
+int ensure_dynamic_lds(int device, const void *func, int bytes);
+
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = true;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) ok = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+// grow-only device block, freed at anrag_index_destroy
+struct DevicePool {
+    char *p = nullptr;
+    int64_t bytes = 0;
+};
+
 }  // namespace anrag
 
 // One GPU's shard.  Everything the kernels touch lives in HBM for the index's lifetime.
@@ -149,6 +183,14 @@ struct anrag_index {
     anrag_candidate *d_w_out = nullptr;
     int64_t wrrf_cap = 0;
 
+    // full-ranking batches (rank_batch.hip): score tiles, ranked row lists, fusion arrays -- one grow-only block
+    anrag::DevicePool rank_pool;
+    // pooled per-call buffers of the host-pointer list entry points (anrag_dense_search with many queries,
+    // anrag_hybrid_search_batch): grow-only, so a steady-state loop allocates nothing
+    anrag::DevicePool call_pool;
+    void *call_pin = nullptr;           // pinned staging of the same calls
+    int64_t call_pin_bytes = 0;
+
     int64_t hbm_bytes = 0;
     int64_t bm25_hbm_bytes = 0;
 
@@ -187,6 +229,9 @@ struct LaunchTimer {
 };
 
 int drain_profile(anrag_index *idx);
+int sync_all(anrag_index *idx);         // wait for the index's three streams
+int settle_pipeline(anrag_index *idx);  // ... only when pipeline queries may be outstanding
+int ensure_pool(anrag_index *idx, DevicePool &pool, int64_t bytes);  // grow-only (contents are NOT kept)
 
 // ---- kernel launchers (each enqueues on `stream`, never syncs)
 int dense_scan_grid(const anrag_index *idx);
@@ -196,7 +241,8 @@ int dense_scan_vgprs(const anrag_index *idx);  // registers of the scan kernel t
 int launch_dense_scan(anrag_index *idx, hipStream_t stream, const float *d_query, int32_t k,
                       const uint32_t *d_allow_bits, float *d_scores_out, int set);
 int launch_dense_scan_group(anrag_index *idx, hipStream_t stream, const float *const *d_queries, int32_t n_queries,
-                            int32_t k, const uint32_t *d_allow_bits, float *d_scores_out, const int *sets);
+                            int32_t k, const uint32_t *d_allow_bits, float *d_scores_out, const int *sets,
+                            int64_t scores_stride = 0);
 int launch_bm25_lists(anrag_index *idx, hipStream_t st, const int32_t *d_terms, int32_t n_terms, int32_t k,
                       const uint32_t *d_allow_bits, double *d_scores_out, int set);
 // Tail of a query, ONE launch (tail.hip): merge the dense block lists of set `set` and/or the BM25 partition

@@ -316,19 +316,19 @@ bool batched_path_applies(const anrag_index *idx, int32_t n_queries, int32_t k) 
 
 static int ensure_batched_workspace(anrag_index *idx, int64_t n_sample /* floats per query */) {
     if (!idx->d_bq) {
-        ANRAG_HIP(hipMalloc(reinterpret_cast<void **>(&idx->d_bq), (size_t)kBQ * idx->dim * sizeof(float)));
-        ANRAG_HIP(hipMalloc(reinterpret_cast<void **>(&idx->d_btau), kBQ * sizeof(float)));
-        ANRAG_HIP(hipMalloc(reinterpret_cast<void **>(&idx->d_bcnt), kBQ * sizeof(int32_t)));
+        ANRAG_HIP(counted_malloc(reinterpret_cast<void **>(&idx->d_bq), (size_t)kBQ * idx->dim * sizeof(float)));
+        ANRAG_HIP(counted_malloc(reinterpret_cast<void **>(&idx->d_btau), kBQ * sizeof(float)));
+        ANRAG_HIP(counted_malloc(reinterpret_cast<void **>(&idx->d_bcnt), kBQ * sizeof(int32_t)));
         ANRAG_HIP(hipMemset(idx->d_bcnt, 0, kBQ * sizeof(int32_t)));  // the counters of padding queries are never reset
-        ANRAG_HIP(hipMalloc(reinterpret_cast<void **>(&idx->d_bflag), kBQ * sizeof(int32_t)));
-        ANRAG_HIP(hipMalloc(reinterpret_cast<void **>(&idx->d_bcand), (size_t)kBQ * kCandCap * sizeof(Cand32)));
+        ANRAG_HIP(counted_malloc(reinterpret_cast<void **>(&idx->d_bflag), kBQ * sizeof(int32_t)));
+        ANRAG_HIP(counted_malloc(reinterpret_cast<void **>(&idx->d_bcand), (size_t)kBQ * kCandCap * sizeof(Cand32)));
         idx->hbm_bytes += (int64_t)kBQ * idx->dim * 4 + (int64_t)kBQ * kCandCap * 8;
     }
     if (idx->bsample_cap < n_sample) {
-        if (idx->d_bsample) (void)hipFree(idx->d_bsample);
+        if (idx->d_bsample) (void)counted_free(idx->d_bsample);
         idx->d_bsample = nullptr;
         idx->bsample_cap = 0;
-        ANRAG_HIP(hipMalloc(reinterpret_cast<void **>(&idx->d_bsample), (size_t)kBQ * n_sample * sizeof(float)));
+        ANRAG_HIP(counted_malloc(reinterpret_cast<void **>(&idx->d_bsample), (size_t)kBQ * n_sample * sizeof(float)));
         idx->bsample_cap = n_sample;
     }
     return ANRAG_OK;
@@ -338,7 +338,7 @@ void free_batched(anrag_index *idx) {
     void *ptrs[] = {idx->d_bq,    idx->d_btau,    idx->d_bcnt,  idx->d_bflag,
                     idx->d_bcand, idx->d_bsample, idx->d_bq_hi, idx->d_bq_lo, idx->d_split_img, idx->d_bq_img};
     for (void *p : ptrs)
-        if (p) (void)hipFree(p);
+        if (p) (void)counted_free(p);
     idx->d_bq = idx->d_btau = idx->d_bsample = nullptr;
     idx->d_bcnt = idx->d_bflag = nullptr;
     idx->d_bcand = idx->d_bq_hi = idx->d_bq_lo = idx->d_split_img = idx->d_bq_img = nullptr;

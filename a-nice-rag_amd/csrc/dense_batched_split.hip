@@ -453,19 +453,19 @@ int batched_passes_split(anrag_index *idx, hipStream_t st, int32_t nq, int32_t k
     const int64_t n_tiles = (n + kSM - 1) / kSM;
     if (!idx->d_split_img) {  // first split-precision pass after a load: the corpus images (free_batched drops them)
         const int64_t bytes = n_tiles * kSM * (int64_t)dim * 4;
-        ANRAG_HIP(hipMalloc(&idx->d_split_img, (size_t)bytes));
+        ANRAG_HIP(counted_malloc(&idx->d_split_img, (size_t)bytes));
         idx->split_img_bytes = bytes;
         idx->hbm_bytes += bytes;
         const int64_t items = n_tiles * kSM * (dim / 8);
         split_images_kernel<<<(unsigned)((items + 255) / 256), 256, 0, st>>>(
             idx->d_emb, n, dim, static_cast<unsigned char *>(idx->d_split_img));
     }
-    if (!idx->d_bq_img) ANRAG_HIP(hipMalloc(&idx->d_bq_img, (size_t)qelems * 4));
+    if (!idx->d_bq_img) ANRAG_HIP(counted_malloc(&idx->d_bq_img, (size_t)qelems * 4));
     split_images_kernel<<<(unsigned)((kBQ * (dim / 8) + 255) / 256), 256, 0, st>>>(
         idx->d_bq, kBQ, dim, static_cast<unsigned char *>(idx->d_bq_img));
     if (!idx->d_bq_hi) {
-        ANRAG_HIP(hipMalloc(&idx->d_bq_hi, (size_t)qelems * 2));
-        ANRAG_HIP(hipMalloc(&idx->d_bq_lo, (size_t)qelems * 2));
+        ANRAG_HIP(counted_malloc(&idx->d_bq_hi, (size_t)qelems * 2));
+        ANRAG_HIP(counted_malloc(&idx->d_bq_lo, (size_t)qelems * 2));
     }
     __bf16 *qh = static_cast<__bf16 *>(idx->d_bq_hi), *ql = static_cast<__bf16 *>(idx->d_bq_lo);
     split_queries_kernel<<<(unsigned)((qelems + 255) / 256), 256, 0, st>>>(idx->d_bq, qelems, qh, ql);

@@ -81,7 +81,8 @@ struct ScanQueries {
 template <int G, int CH, int R, bool FILTER, bool SCORES, int THREADS = kScanThreads>
 __global__ __launch_bounds__(THREADS) void dense_scan_kernel(
     const float *__restrict__ emb, ScanQueries Q, int64_t n_rows, int32_t dim, int32_t k,
-    const uint16_t *__restrict__ src, const uint32_t *__restrict__ allow_bits, float *__restrict__ scores_out) {
+    const uint16_t *__restrict__ src, const uint32_t *__restrict__ allow_bits, float *__restrict__ scores_out,
+    int64_t scores_stride) {
     constexpr int GROUPS = kWave / G;  // rows per wave-load
     constexpr int RW = GROUPS * R;     // rows per wave iteration
     constexpr int WAVES = THREADS / kWave;
@@ -160,12 +161,13 @@ __global__ __launch_bounds__(THREADS) void dense_scan_kernel(
     };
     float part[R];        // SPLIT == 2: the first half's partial dot products
     uint32_t part_sid[R];
+    int32_t qi = 0;  // the query whose batch is being reduced (SCORES: query qi's scores start at qi * scores_stride)
     auto finish_row = [&](int64_t row, float acc, uint32_t sid) {
         acc = nan_first(group_sum<G>(acc));
         bool ok = row < n_rows;
         if constexpr (FILTER) ok = ok && source_ok(lds_allow, sid);
         if constexpr (SCORES) {
-            if (leader && row < n_rows) scores_out[row] = ok ? acc : neg_inf<float>();
+            if (leader && row < n_rows) scores_out[(int64_t)qi * scores_stride + row] = ok ? acc : neg_inf<float>();
         } else {
             const uint32_t r32 = (uint32_t)row;
             top.offer_lanes(leader && ok && top.admits(acc, r32), acc, r32);
@@ -203,10 +205,9 @@ __global__ __launch_bounds__(THREADS) void dense_scan_kernel(
     const int64_t base0 = ((int64_t)blockIdx.x * WAVES + wave) * RW;
     if (base0 >= n_rows) {  // a wave without rows (tiny corpora): empty lists
         top.init(1);
-        for (int32_t qi = 0; qi < Q.n; ++qi) flush(qi);
+        for (int32_t qe = 0; qe < Q.n; ++qe) flush(qe);
         return;
     }
-    int32_t qi = 0;
     fetch_query(0);
     next_query(0);
     Batch b0, b1;
@@ -436,14 +437,15 @@ int dense_scan_vgprs(const anrag_index *idx) {
 
 int launch_dense_scan(anrag_index *idx, hipStream_t st, const float *d_query, int32_t k,
                       const uint32_t *d_allow_bits, float *d_scores_out, int set) {
-    return launch_dense_scan_group(idx, st, &d_query, 1, k, d_allow_bits, d_scores_out, &set);
+    return launch_dense_scan_group(idx, st, &d_query, 1, k, d_allow_bits, d_scores_out, &set, 0);
 }
 
-// n <= kScanGroupMax queries in ONE launch, query i into block-list set sets[i] (d_scores_out: n == 1 only)
+// n <= kScanGroupMax queries in ONE launch, query i into block-list set sets[i] -- or, with d_scores_out, every score
+// of query i to d_scores_out + i * scores_stride (the full-ranking tile, rank_batch.hip)
 int launch_dense_scan_group(anrag_index *idx, hipStream_t st, const float *const *d_queries, int32_t n_queries, int32_t k,
-                            const uint32_t *d_allow_bits, float *d_scores_out, const int *sets) {
+                            const uint32_t *d_allow_bits, float *d_scores_out, const int *sets, int64_t scores_stride) {
     ANRAG_REQUIRE(n_queries >= 1 && n_queries <= kScanGroupMax, "scan group of %d queries", n_queries);
-    ANRAG_REQUIRE(!d_scores_out || n_queries == 1, "score output serves one query per launch");
+    ANRAG_REQUIRE(!d_scores_out || n_queries == 1 || scores_stride >= idx->n_rows, "score tile rows overlap");
     const int64_t n = idx->n_rows;
     ScanQueries Q;
     Q.n = n_queries;
@@ -465,7 +467,7 @@ int launch_dense_scan_group(anrag_index *idx, hipStream_t st, const float *const
             using S = decltype(shape);
 #define ANRAG_SCAN(F, SC)                                                                                  \
     dense_scan_kernel<S::kG, S::kCH, S::kR, F, SC><<<grid, kScanThreads, 0, st>>>(                            \
-        idx->d_emb, Q, idx->n_rows, idx->dim, k, idx->d_dense_src, allow, d_scores_out)
+        idx->d_emb, Q, idx->n_rows, idx->dim, k, idx->d_dense_src, allow, d_scores_out, scores_stride)
             if (d_scores_out) {
                 if (allow) ANRAG_SCAN(true, true); else ANRAG_SCAN(false, true);
             } else {
@@ -476,9 +478,9 @@ int launch_dense_scan_group(anrag_index *idx, hipStream_t st, const float *const
         if (!done) {  // odd dimensions: one launch per query
             (void)d_query; (void)blk_s; (void)blk_r;
             for (int i = 0; i < n_queries; ++i)
-                dense_scan_topk_generic_kernel<<<grid, kScanThreads, 0, st>>>(idx->d_emb, Q.q[i], n, d, k,
-                                                                              idx->d_dense_src, allow, Q.blk_s[i],
-                                                                              Q.blk_r[i], d_scores_out);
+                dense_scan_topk_generic_kernel<<<grid, kScanThreads, 0, st>>>(
+                    idx->d_emb, Q.q[i], n, d, k, idx->d_dense_src, allow, Q.blk_s[i], Q.blk_r[i],
+                    d_scores_out ? d_scores_out + (int64_t)i * scores_stride : nullptr);
         }
         ANRAG_HIP(hipGetLastError());
     }

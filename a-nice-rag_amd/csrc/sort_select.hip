@@ -41,10 +41,10 @@ static int sort_scores(anrag_index *idx, hipStream_t st, const S *d_scores, int6
                        const int64_t *doc_of_row, int64_t doc_base, anrag_candidate **d_out) {
     const int64_t need = n * (int64_t)(sizeof(S) + sizeof(uint32_t)) + k * (int64_t)sizeof(anrag_candidate) + 256;
     if (idx->sort_buf_bytes < need) {
-        if (idx->d_sort_buf) (void)hipFree(idx->d_sort_buf);
+        if (idx->d_sort_buf) (void)counted_free(idx->d_sort_buf);
         idx->d_sort_buf = nullptr;
         idx->sort_buf_bytes = 0;
-        ANRAG_HIP(hipMalloc(&idx->d_sort_buf, (size_t)need));
+        ANRAG_HIP(counted_malloc(&idx->d_sort_buf, (size_t)need));
         idx->sort_buf_bytes = need;
     }
     char *base = static_cast<char *>(idx->d_sort_buf);
@@ -56,10 +56,10 @@ static int sort_scores(anrag_index *idx, hipStream_t st, const S *d_scores, int6
     ANRAG_HIP(rocprim::radix_sort_pairs_desc(nullptr, tmp, d_scores, keys_out, rows_in, rows_out, (size_t)n, 0,
                                              8 * sizeof(S), st));
     if ((int64_t)tmp > idx->sort_tmp_bytes) {
-        if (idx->d_sort_tmp) (void)hipFree(idx->d_sort_tmp);
+        if (idx->d_sort_tmp) (void)counted_free(idx->d_sort_tmp);
         idx->d_sort_tmp = nullptr;
         idx->sort_tmp_bytes = 0;
-        ANRAG_HIP(hipMalloc(&idx->d_sort_tmp, tmp));
+        ANRAG_HIP(counted_malloc(&idx->d_sort_tmp, tmp));
         idx->sort_tmp_bytes = (int64_t)tmp;
     }
     {
@@ -99,7 +99,7 @@ int dense_search_large_k(anrag_index *idx, hipStream_t st, const float *h_querie
                          const uint32_t *d_allow_bits, int64_t *out_doc, float *out_score, int32_t *out_count) {
     const int64_t n = idx->n_rows;
     if (!idx->d_scores_f32) {
-        ANRAG_HIP(hipMalloc(reinterpret_cast<void **>(&idx->d_scores_f32), (size_t)n * sizeof(float)));
+        ANRAG_HIP(counted_malloc(reinterpret_cast<void **>(&idx->d_scores_f32), (size_t)n * sizeof(float)));
         idx->hbm_bytes += n * 4;
     }
     const int64_t have = std::min<int64_t>(k, n);
@@ -123,10 +123,10 @@ int dense_search_f64(anrag_index *idx, hipStream_t st, const double *h_query, in
                      int64_t *out_doc, double *out_score, int32_t *out_count) {
     const int64_t n = idx->n_rows;
     if (!idx->d_dense_scores_f64) {
-        ANRAG_HIP(hipMalloc(reinterpret_cast<void **>(&idx->d_dense_scores_f64), (size_t)n * sizeof(double)));
+        ANRAG_HIP(counted_malloc(reinterpret_cast<void **>(&idx->d_dense_scores_f64), (size_t)n * sizeof(double)));
         idx->hbm_bytes += n * 8;
     }
-    if (!idx->d_query_f64) ANRAG_HIP(hipMalloc(reinterpret_cast<void **>(&idx->d_query_f64), 65536 * sizeof(double)));
+    if (!idx->d_query_f64) ANRAG_HIP(counted_malloc(reinterpret_cast<void **>(&idx->d_query_f64), 65536 * sizeof(double)));
     ANRAG_HIP(hipMemcpyAsync(idx->d_query_f64, h_query, (size_t)idx->dim * sizeof(double), hipMemcpyHostToDevice, st));
     int rc = launch_dense_scores_f64(idx, st, idx->d_query_f64, d_allow_bits, idx->d_dense_scores_f64);
     if (rc) return rc;
@@ -141,7 +141,7 @@ int bm25_search_large_k(anrag_index *idx, hipStream_t st, const int32_t *d_terms
                         const uint32_t *d_allow_bits, int64_t *out_doc, double *out_score, int32_t *out_count) {
     const int64_t n = idx->n_docs;
     if (!idx->d_scores_f64) {
-        ANRAG_HIP(hipMalloc(reinterpret_cast<void **>(&idx->d_scores_f64), (size_t)n * sizeof(double)));
+        ANRAG_HIP(counted_malloc(reinterpret_cast<void **>(&idx->d_scores_f64), (size_t)n * sizeof(double)));
         idx->hbm_bytes += n * 8;
         idx->bm25_hbm_bytes += n * 8;
     }
@@ -214,10 +214,10 @@ int wrrf_sorted(anrag_index *idx, hipStream_t st, const int64_t *d_ids, const do
     const int64_t per = 8 + 4 + 4 + 8 + 8 + 4 + 4 + 8 + 8 + 4;  // the arrays carved below
     const int64_t need = (int64_t)m * per + 16 * 256;
     if (idx->w_blob_bytes < need) {
-        if (idx->d_w_blob) (void)hipFree(idx->d_w_blob);
+        if (idx->d_w_blob) (void)counted_free(idx->d_w_blob);
         idx->d_w_blob = nullptr;
         idx->w_blob_bytes = 0;
-        ANRAG_HIP(hipMalloc(&idx->d_w_blob, (size_t)need));
+        ANRAG_HIP(counted_malloc(&idx->d_w_blob, (size_t)need));
         idx->w_blob_bytes = need;
     }
     char *at = static_cast<char *>(idx->d_w_blob);
@@ -243,10 +243,10 @@ int wrrf_sorted(anrag_index *idx, hipStream_t st, const int64_t *d_ids, const do
     ANRAG_HIP(rocprim::radix_sort_pairs_desc(nullptr, t3, key2, key2_sorted, order1, order2, (size_t)m, 0, 64, st));
     const size_t tmp = std::max(t1, std::max(t2, t3));
     if ((int64_t)tmp > idx->sort_tmp_bytes) {
-        if (idx->d_sort_tmp) (void)hipFree(idx->d_sort_tmp);
+        if (idx->d_sort_tmp) (void)counted_free(idx->d_sort_tmp);
         idx->d_sort_tmp = nullptr;
         idx->sort_tmp_bytes = 0;
-        ANRAG_HIP(hipMalloc(&idx->d_sort_tmp, tmp));
+        ANRAG_HIP(counted_malloc(&idx->d_sort_tmp, tmp));
         idx->sort_tmp_bytes = (int64_t)tmp;
     }
     const unsigned blocks = (unsigned)((m + 255) / 256);

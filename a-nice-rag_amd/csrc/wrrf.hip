@@ -145,7 +145,7 @@ void free_wrrf_scratch(anrag_index *idx) {
     idx->d_w_blob = nullptr;
     idx->w_blob_bytes = 0;
     for (void *p : ptrs)
-        if (p) (void)hipFree(p);
+        if (p) (void)counted_free(p);
     idx->d_w_ids = idx->d_w_in = nullptr;
     idx->d_w_contrib = idx->d_w_score = nullptr;
     idx->d_w_first = idx->d_w_count = nullptr;
@@ -157,13 +157,13 @@ int ensure_wrrf_scratch(anrag_index *idx, int64_t m) {
     if (idx->wrrf_cap >= m && idx->d_w_count) return ANRAG_OK;
     free_wrrf_scratch(idx);
     const int64_t cap = m < 4096 ? 4096 : m;
-    ANRAG_HIP(hipMalloc(reinterpret_cast<void **>(&idx->d_w_ids), (size_t)cap * 8));
-    ANRAG_HIP(hipMalloc(reinterpret_cast<void **>(&idx->d_w_in), (size_t)cap * 8));
-    ANRAG_HIP(hipMalloc(reinterpret_cast<void **>(&idx->d_w_contrib), (size_t)cap * 8));
-    ANRAG_HIP(hipMalloc(reinterpret_cast<void **>(&idx->d_w_score), (size_t)cap * 8));
-    ANRAG_HIP(hipMalloc(reinterpret_cast<void **>(&idx->d_w_first), (size_t)cap * 4));
-    ANRAG_HIP(hipMalloc(reinterpret_cast<void **>(&idx->d_w_out), (size_t)cap * sizeof(anrag_candidate)));
-    ANRAG_HIP(hipMalloc(reinterpret_cast<void **>(&idx->d_w_count), 64));
+    ANRAG_HIP(counted_malloc(reinterpret_cast<void **>(&idx->d_w_ids), (size_t)cap * 8));
+    ANRAG_HIP(counted_malloc(reinterpret_cast<void **>(&idx->d_w_in), (size_t)cap * 8));
+    ANRAG_HIP(counted_malloc(reinterpret_cast<void **>(&idx->d_w_contrib), (size_t)cap * 8));
+    ANRAG_HIP(counted_malloc(reinterpret_cast<void **>(&idx->d_w_score), (size_t)cap * 8));
+    ANRAG_HIP(counted_malloc(reinterpret_cast<void **>(&idx->d_w_first), (size_t)cap * 4));
+    ANRAG_HIP(counted_malloc(reinterpret_cast<void **>(&idx->d_w_out), (size_t)cap * sizeof(anrag_candidate)));
+    ANRAG_HIP(counted_malloc(reinterpret_cast<void **>(&idx->d_w_count), 64));
     idx->wrrf_cap = cap;
     return ANRAG_OK;
 }

@@ -24,6 +24,75 @@ def _allow_bytes(allow) -> Tuple[Optional[np.ndarray], int]:
     return a, int(a.size)
 
 
+def rank_caps() -> Tuple[int, int]:
+    """Longest list `rank_batch` returns for a dense leg / for a BM25 leg or a fused ranking."""
+    a, b = C.c_int32(), C.c_int32()
+    nat.check(nat.load_library().anrag_rank_caps(C.byref(a), C.byref(b)))
+    return a.value, b.value
+
+
+def rank_batch(legs: Sequence[dict], n_queries: int, similarity_k: int, wrrf_k: float, top_n: int,
+               id_space: int = 0, want_scores: bool = False, expect=None, want_ids: bool = True):
+    """`anrag_rank_batch`: full-ranking retrieval (large k) for a LIST of queries, every step on the device.
+    `legs`: dicts in the reference's list order (dense models first, BM25 last) with
+        index (Index), weight, allow (uint8 per source or None), doc_of_row (int64 per row or None), and either
+        queries (float32 [nq, dim]) or term_lists (one int32 sequence per query; an empty one = no BM25 for that query).
+    `expect` (int64 per query): also return the 1-based rank of that document in each answer (-1: absent);
+    `want_ids=False` then skips the id lists altogether.
+    -> (ids [nq, top_n] int64 (-1 padded) or None, scores [nq, top_n] float64 or None, counts [nq] int32)
+       -- plus ranks [nq] int32 as a fourth element when `expect` is given."""
+    lib = nat.load_library()
+    arr = (nat.RankLeg * len(legs))()
+    keep = []
+    for i, leg in enumerate(legs):
+        ix = leg["index"]
+        arr[i].idx = ix.handle
+        arr[i].weight = float(leg["weight"])
+        allow, ns = _allow_bytes(leg.get("allow"))
+        keep.append(allow)
+        arr[i].allow_source = nat.ptr(allow)
+        arr[i].n_sources = ns
+        dmap = leg.get("doc_of_row")
+        if dmap is not None:
+            dmap = np.ascontiguousarray(dmap, dtype=np.int64)
+            keep.append(dmap)
+        arr[i].doc_of_row = nat.ptr(dmap)
+        if leg.get("queries") is not None:
+            q = _f32(leg["queries"])
+            if q.ndim == 1:
+                q = q[None, :]
+            assert q.shape == (n_queries, ix.dim), f"leg {i}: queries {q.shape} != ({n_queries}, {ix.dim})"
+            keep.append(q)
+            arr[i].kind = nat.LEG_DENSE
+            arr[i].queries = q.ctypes.data
+        else:
+            term_lists = leg["term_lists"]
+            assert len(term_lists) == n_queries
+            offsets = np.zeros(n_queries + 1, dtype=np.int64)
+            np.cumsum([len(t) for t in term_lists], out=offsets[1:])
+            terms = (np.concatenate([np.asarray(t, dtype=np.int32).reshape(-1) for t in term_lists]).astype(np.int32)
+                     if offsets[-1] else np.zeros(1, np.int32))
+            terms = np.ascontiguousarray(terms)
+            keep += [offsets, terms]
+            arr[i].kind = nat.LEG_BM25
+            arr[i].term_ids = terms.ctypes.data
+            arr[i].term_offsets = offsets.ctypes.data
+    out_id = np.empty((n_queries, top_n), np.int64) if want_ids else None
+    out_score = np.empty((n_queries, top_n), np.float64) if want_scores and want_ids else None
+    count = np.zeros(n_queries, np.int32)
+    exp = ranks = None
+    if expect is not None:
+        exp = np.ascontiguousarray(expect, dtype=np.int64)
+        assert exp.shape == (n_queries,)
+        ranks = np.empty(n_queries, np.int32)
+    nat.check(lib.anrag_rank_batch(C.cast(arr, C.c_void_p), len(legs), int(n_queries), int(similarity_k), float(wrrf_k),
+                                   int(top_n), int(id_space), nat.ptr(out_id), nat.ptr(out_score),
+                                   count.ctypes.data, nat.ptr(exp), nat.ptr(ranks)))
+    if expect is not None:
+        return out_id, out_score, count, ranks
+    return out_id, out_score, count
+
+
 class Index:
     """Owns an `anrag_index*`.  Not copyable; `close()` (or GC) frees the HBM."""
 

@@ -274,6 +274,57 @@ int anrag_hybrid_search_batch(anrag_index *idx, const float *queries, const int3
                               const uint8_t *allow_bm25, int32_t n_bm25_sources, int64_t *out_id,
                               double *out_score, int32_t *out_count);
 
+/* ------------------------------------------------------------------ full ranking for lists of queries
+ * retrieval_eval.py runs 7 of its 9 configurations with similarity_k = common_sections_n = 12000 -- "rank
+ * everything" -- over ~8,000 queries each (src/retrieval_eval.py:142-143, :155-156, :366-378), one
+ * retrieve_documents call per query.  This is the body of that call (src/query_rag_retrieval.py:197-370: every
+ * active dense model's similarity search, the BM25 search, weighted RRF, truncation to common_sections_n) for a
+ * LIST of queries, entirely on the device: score tiles, a per-(query, leg) radix select + sort, fusion over row
+ * lists, one host sync per chunk of queries (rank_batch.hip).
+ *
+ * A LEG is one ranked list per query (the reference's `ranked_lists` entries, in the reference's order: dense models
+ * first, BM25 last):
+ *   kind ANRAG_LEG_DENSE  idx's dense rows, ranked by fp32 dot product with queries[q] (host, [n_queries][dim]) --
+ *                         the arithmetic of anrag_dense_search, bit for bit
+ *   kind ANRAG_LEG_BM25   idx's BM25 rows, ranked by BM25 score of query q's term ids
+ *                         term_ids[term_offsets[q] .. term_offsets[q+1]) (host); a query WITHOUT term ids has no such
+ *                         leg, as the reference skips BM25 for it (src/search_engine.py:216-217)
+ *   allow_source / n_sources   as for anrag_dense_search (NULL = no filter); a leg the filter empties is dropped for
+ *                         that query like any empty list (query_rag_retrieval.py:213, :326)
+ *   doc_of_row            host, one int64 per row of the leg: the document id of the row in an id space shared by the
+ *                         legs (what the chunk-id strings are to the reference's fusion); NULL = the row number.
+ *                         With two or more legs every id must lie in [0, id_space) and a leg must not name a
+ *                         document twice (ANRAG_ERR_INVALID otherwise)
+ *   weight                model_weights[name] (> 0; the caller leaves out legs of weight 0 as the reference does)
+ * Each leg keeps its best min(similarity_k, allowed rows) rows by (score desc, row asc).  One leg: out = its first
+ * top_n documents (query_rag_retrieval.py:363-366), out_score = their leg scores.  Several: weighted RRF with wrrf_k,
+ * stable by first insertion (search_engine.py:21-34, fp64, bit-exact), first top_n; out_score = fused scores.
+ * out_id (nullable) / out_score (nullable, needs out_id) [n_queries][top_n], tail -1 / -inf; out_count [n_queries].
+ * expect_id / out_rank (nullable, together) [n_queries]: out_rank[q] = 1-based position of document expect_id[q] in
+ * query q's answer, -1 if it is not there -- what retrieval_eval.py:75-82 looks for in the returned list; with
+ * out_id == NULL only counts and ranks come back (an evaluation run over thousands of queries needs nothing else).
+ * Envelope: min(similarity_k, rows) <= 16384 for a dense leg, <= 13312 for a BM25 leg, min(top_n, entries) <= 13312
+ * when fusing (anrag_rank_caps); all legs on one device.  Outside it: ANRAG_ERR_INVALID -- use the per-query entry
+ * points (any k). */
+#define ANRAG_LEG_DENSE 0
+#define ANRAG_LEG_BM25 1
+typedef struct anrag_rank_leg {
+    anrag_index *idx;
+    int32_t kind;
+    const float *queries;
+    const int32_t *term_ids;
+    const int64_t *term_offsets;
+    const uint8_t *allow_source;
+    int32_t n_sources;
+    const int64_t *doc_of_row;
+    double weight;
+} anrag_rank_leg;
+int anrag_rank_batch(const anrag_rank_leg *legs, int32_t n_legs, int32_t n_queries, int32_t similarity_k,
+                     double wrrf_k, int32_t top_n, int64_t id_space, int64_t *out_id, double *out_score,
+                     int32_t *out_count, const int64_t *expect_id, int32_t *out_rank);
+/* Largest list a dense (fp32 scores) / BM25 or fused (fp64 scores) ranking of anrag_rank_batch can return. */
+int anrag_rank_caps(int32_t *out_k_max_fp32, int32_t *out_k_max_fp64);
+
 /* ------------------------------------------------------------------ sharded merge
  * After an all-gather of every shard's k candidates: merge n_lists sorted lists of
  * k records each into the global top-k (score desc, doc asc -- row order is
@@ -351,6 +402,9 @@ int anrag_profile_read_units(anrag_index *idx, int kernel_id, int64_t *out_units
 /* Shape facts a caller needs for roofline arithmetic. */
 int anrag_index_info(anrag_index *idx, int64_t *dense_rows, int32_t *dense_dim,
                      int64_t *bm25_docs, int64_t *bm25_postings, int64_t *hbm_bytes);
+/* Device / pinned-host allocations and releases the library has made so far (process-wide; each one
+ * synchronises the device).  A steady-state query loop must not move it: tests/test_gpu_no_alloc.py. */
+int anrag_debug_alloc_calls(int64_t *out_calls);
 
 #ifdef __cplusplus
 }
