@@ -68,6 +68,7 @@ _SIGNATURES = {
     "anrag_bm25_load": [_p, _p, _i64, _p, _p, _p, _p, _i64, _f64, _f64, _f64, _p, _p, _i64],
     "anrag_bm25_search": [_p, _p, _i32, _i32, _p, _i32, _p, _p, _p],
     "anrag_bm25_search_device": [_p, _p, _i32, _i32, _p, _p],
+    "anrag_bm25_search_group_device": [_p, _p, _p, _i32, _i32, _p, _p],
     "anrag_bm25_scores": [_p, _p, _i32, _p],
     "anrag_wrrf": [_p, _p, _p, _p, _i32, _f64, _i32, _p, _p, _p],
     "anrag_hybrid_search": [_p, _p, _p, _i32, _i32, _f64, _f64, _f64, _i32, _p, _i32, _p, _i32, _p, _p, _p],

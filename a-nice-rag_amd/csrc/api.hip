@@ -596,6 +596,27 @@ int anrag_bm25_search_device(anrag_index *idx, const int32_t *d_term_ids, int32_
     return hybrid_enqueue_group(idx, kTailCandidates, &q, 1, k, 0.0, 1.0, 0.0, 0, nullptr, d_allow_bits);
 }
 
+int anrag_bm25_search_group_device(anrag_index *idx, const int32_t *const *d_term_ids, const int32_t *n_terms,
+                                   int32_t n_queries, int32_t k, const uint32_t *d_allow_bits,
+                                   anrag_candidate *const *d_out) {
+    ANRAG_ENTER(idx);
+    ANRAG_REQUIRE(idx->d_post_doc != nullptr, "BM25 search before anrag_bm25_load");
+    ANRAG_REQUIRE(d_term_ids && n_terms && d_out, "NULL operand");
+    ANRAG_REQUIRE(n_queries >= 1 && n_queries <= 4096, "n_queries %d out of range", n_queries);
+    ANRAG_REQUIRE(k > 0 && k <= ANRAG_FUSED_K_MAX, "device path serves 1 <= k <= %d (got %d)", ANRAG_FUSED_K_MAX, k);
+    for (int32_t i = 0; i < n_queries; ++i)
+        ANRAG_REQUIRE(d_out[i] && n_terms[i] >= 0 && (n_terms[i] == 0 || d_term_ids[i]),
+                      "query %d: needs an output block and term ids for its n_terms", i);
+    for (int32_t q0 = 0; q0 < n_queries; q0 += kScanGroup) {
+        const int n = n_queries - q0 < kScanGroup ? n_queries - q0 : kScanGroup;
+        GroupQuery g[kScanGroup];
+        for (int i = 0; i < n; ++i) g[i] = GroupQuery{nullptr, d_term_ids[q0 + i], n_terms[q0 + i], d_out[q0 + i], nullptr};
+        int rc = hybrid_enqueue_group(idx, kTailCandidates, g, n, k, 0.0, 1.0, 0.0, 0, nullptr, d_allow_bits);
+        if (rc) return rc;
+    }
+    return ANRAG_OK;
+}
+
 int anrag_bm25_search(anrag_index *idx, const int32_t *term_ids, int32_t n_terms, int32_t k,
                       const uint8_t *allow_source, int32_t n_sources, int64_t *out_doc, double *out_score,
                       int32_t *out_count) {
@@ -760,9 +781,17 @@ static int hybrid_enqueue_group(anrag_index *idx, TailMode tail, const GroupQuer
         ANRAG_HIP(hipEventRecord(idx->ev_scan[slot[0]], P));
     }
     hipStream_t T = tail == kTailFuse ? S : F;
-    for (int i = 0; i < n; ++i) {
-        if (!use_bm25[i]) continue;
-        if ((rc = launch_bm25_lists(idx, S, q[i].d_terms, q[i].n_terms, k, d_allow_bm25, nullptr, slot[i]))) return rc;
+    {  // the BM25 legs of the group: one launch, a workgroup set per query
+        const int32_t *bt[kScanGroupMax];
+        int32_t bn[kScanGroupMax];
+        int bs[kScanGroupMax], nb = 0;
+        for (int i = 0; i < n; ++i) {
+            if (!use_bm25[i]) continue;
+            bt[nb] = q[i].d_terms;
+            bn[nb] = q[i].n_terms;
+            bs[nb++] = slot[i];
+        }
+        if (nb > 0 && (rc = launch_bm25_lists_group(idx, S, bt, bn, nb, k, d_allow_bm25, nullptr, bs))) return rc;
     }
     if (T != S) {
         bool any = false;
@@ -773,11 +802,19 @@ static int hybrid_enqueue_group(anrag_index *idx, TailMode tail, const GroupQuer
         }
     }
     if (use_dense) ANRAG_HIP(hipStreamWaitEvent(T, idx->ev_scan[slot[0]], 0));
-    for (int i = 0; i < n; ++i) {
-        if ((rc = launch_tail(idx, T, slot[i], use_dense, use_bm25[i], k, tail, w_dense, w_bm25, wrrf_k, top_n, q[i].d_out,
-                              q[i].d_count)))
+    {  // the group's tails: one launch, a workgroup per query
+        anrag_candidate *outs[kScanGroupMax];
+        int32_t *counts[kScanGroupMax];
+        bool any_count = false;
+        for (int i = 0; i < n; ++i) {
+            outs[i] = q[i].d_out;
+            counts[i] = q[i].d_count;
+            any_count = any_count || q[i].d_count != nullptr;
+        }
+        if ((rc = launch_tail_group(idx, T, slot, use_dense, use_bm25, n, k, tail, w_dense, w_bm25, wrrf_k, top_n, outs,
+                                    any_count ? counts : nullptr)))
             return rc;
-        ANRAG_HIP(hipEventRecord(idx->ev_fused[slot[i]], T));
+        for (int i = 0; i < n; ++i) ANRAG_HIP(hipEventRecord(idx->ev_fused[slot[i]], T));
     }
     return ANRAG_OK;
 }

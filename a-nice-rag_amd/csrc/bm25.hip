@@ -115,13 +115,28 @@ static_assert((kFrequentDf + kBm25ThreadsSmall - 1) / kBm25ThreadsSmall <= kRoun
 // Register budget of the 1,024-thread form: its 16 waves (4 per SIMD) must fit NEXT TO a scan workgroup (one wave of up
 // to 104 VGPRs per SIMD, dense_scan.hip), or K3 can only run between scans instead of under them: 5 waves per SIMD
 // asked for = at most 96 VGPRs each.
+// The queries of one launch (blockIdx.y): every query has its own workgroups, one per partition, so a launch of a
+// GROUP pays the launch once and a CU goes from a workgroup of query i straight to one of query i+1 (the hybrid
+// pipeline's exchange groups, anrag_hybrid_search_batch, the full-ranking tiles of rank_batch.hip).
+struct Bm25Queries {
+    const int32_t *terms[kScanGroupMax];
+    int32_t n_terms[kScanGroupMax];
+    double *blk_score[kScanGroupMax];   // per-partition lists of the query's slot (selection form)
+    uint32_t *blk_row[kScanGroupMax];
+    double *scores[kScanGroupMax];      // n_docs scores (SCORES form)
+};
+
 template <bool FILTER, bool SCORES, int THREADS>
 __global__ __launch_bounds__(THREADS, THREADS == kBm25Threads ? 5 : 1) void bm25_kernel(
     const int64_t *__restrict__ indptr, const int32_t *__restrict__ post_doc, const double *__restrict__ impact,
     const double *__restrict__ idf, const int32_t *__restrict__ part_slot, const int32_t *__restrict__ part_ptr,
-    int32_t n_parts, int32_t part_docs, int64_t n_docs, int64_t n_vocab, const int32_t *__restrict__ terms,
-    int32_t n_terms, int32_t k, const uint16_t *__restrict__ src, const uint32_t *__restrict__ allow_bits,
-    double *__restrict__ blk_score, uint32_t *__restrict__ blk_row, double *__restrict__ scores_out, int64_t sentinel) {
+    int32_t n_parts, int32_t part_docs, int64_t n_docs, int64_t n_vocab, Bm25Queries Q, int32_t k,
+    const uint16_t *__restrict__ src, const uint32_t *__restrict__ allow_bits, int64_t sentinel) {
+    const int32_t *__restrict__ terms = Q.terms[blockIdx.y];
+    const int32_t n_terms = Q.n_terms[blockIdx.y];
+    double *__restrict__ blk_score = Q.blk_score[blockIdx.y];
+    uint32_t *__restrict__ blk_row = Q.blk_row[blockIdx.y];
+    double *__restrict__ scores_out = Q.scores[blockIdx.y];
     extern __shared__ __attribute__((aligned(16))) unsigned char bm25_lds[];
     double *slice = reinterpret_cast<double *>(bm25_lds);
     constexpr int WAVES = THREADS / kWave;
@@ -634,37 +649,41 @@ int bm25_load(anrag_index *idx, const int64_t *indptr, int64_t n_terms, const in
     return ANRAG_OK;
 }
 
-// K3 only: per-partition lists (or every score) are left in HBM; the tail kernel finishes the top-k
-int launch_bm25_lists(anrag_index *idx, hipStream_t st, const int32_t *d_terms, int32_t n_terms, int32_t k,
-                      const uint32_t *d_allow_bits, double *d_scores_out, int set) {
+// K3 only: per-partition lists (or every score) are left in HBM; the tail kernel finishes the top-k.
+// n <= kScanGroupMax queries in ONE launch: query i's lists into list set sets[i], or (d_scores_out given) its n_docs
+// scores to d_scores_out[i].
+int launch_bm25_lists_group(anrag_index *idx, hipStream_t st, const int32_t *const *d_terms, const int32_t *n_terms,
+                            int32_t n_queries, int32_t k, const uint32_t *d_allow_bits, double *const *d_scores_out,
+                            const int *sets) {
+    ANRAG_REQUIRE(n_queries >= 1 && n_queries <= kScanGroupMax, "BM25 group of %d queries", n_queries);
     const uint32_t *allow = idx->d_bm25_src ? d_allow_bits : nullptr;
-    static bool attr_set = false;
-    if (!attr_set) {  // dynamic LDS is asked for explicitly (up to 60 KB per workgroup)
-#define ANRAG_BM25_ATTR(F, S, T)                                                                      \
-    ANRAG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&bm25_kernel<F, S, T>),              \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, bm25_lds_bytes(T)))
-        ANRAG_BM25_ATTR(false, false, kBm25Threads);
-        ANRAG_BM25_ATTR(false, true, kBm25Threads);
-        ANRAG_BM25_ATTR(true, false, kBm25Threads);
-        ANRAG_BM25_ATTR(true, true, kBm25Threads);
-        ANRAG_BM25_ATTR(false, false, kBm25ThreadsSmall);
-        ANRAG_BM25_ATTR(false, true, kBm25ThreadsSmall);
-        ANRAG_BM25_ATTR(true, false, kBm25ThreadsSmall);
-        ANRAG_BM25_ATTR(true, true, kBm25ThreadsSmall);
-#undef ANRAG_BM25_ATTR
-        attr_set = true;
+    int rc;
+    // dynamic LDS is asked for explicitly (up to 60 KB per workgroup), per device
+#define ANRAG_BM25_ATTR(F, S, T)                                                                                     \
+    if ((rc = ensure_dynamic_lds(idx->device, reinterpret_cast<const void *>(&bm25_kernel<F, S, T>), bm25_lds_bytes(T)))) \
+        return rc
+    Bm25Queries Q;
+    for (int i = 0; i < kScanGroupMax; ++i) {
+        const int j = i < n_queries ? i : 0;
+        Q.terms[i] = d_terms[j];
+        Q.n_terms[i] = n_terms[j];
+        Q.blk_score[i] = idx->d_blk_score_f64 + (int64_t)(sets ? sets[j] : 0) * idx->n_parts * kListLen;
+        Q.blk_row[i] = idx->d_blk_row_b + (int64_t)(sets ? sets[j] : 0) * idx->n_parts * kListLen;
+        Q.scores[i] = d_scores_out ? d_scores_out[j] : nullptr;
     }
-    double *blk_s = idx->d_blk_score_f64 + (int64_t)set * idx->n_parts * kListLen;
-    uint32_t *blk_r = idx->d_blk_row_b + (int64_t)set * idx->n_parts * kListLen;
     {
-        LaunchTimer t(idx, ANRAG_KERNEL_BM25, st);
+        LaunchTimer t(idx, ANRAG_KERNEL_BM25, st, n_queries);
         // partitions of <= 1,024 documents: the 256-thread form (one wave per SIMD, cheaper barriers)
         const bool small = idx->part_docs <= kPostPerThread * kBm25ThreadsSmall;
+        const dim3 grid((unsigned)idx->n_parts, (unsigned)n_queries);
 #define ANRAG_BM25_T(F, S, T)                                                                                     \
-    bm25_kernel<F, S, T><<<idx->n_parts, T, bm25_lds_bytes(T), st>>>(                                              \
-        idx->d_indptr, idx->d_post_doc, idx->d_post_impact, idx->d_idf, idx->d_part_slot, idx->d_part_ptr,        \
-        idx->n_parts, idx->part_docs, idx->n_docs, idx->n_terms, d_terms, n_terms, k, idx->d_bm25_src, allow,     \
-        blk_s, blk_r, d_scores_out, idx->n_postings)
+    do {                                                                                                          \
+        ANRAG_BM25_ATTR(F, S, T);                                                                                 \
+        bm25_kernel<F, S, T><<<grid, T, bm25_lds_bytes(T), st>>>(                                                  \
+            idx->d_indptr, idx->d_post_doc, idx->d_post_impact, idx->d_idf, idx->d_part_slot, idx->d_part_ptr,    \
+            idx->n_parts, idx->part_docs, idx->n_docs, idx->n_terms, Q, k, idx->d_bm25_src, allow,                \
+            idx->n_postings);                                                                                     \
+    } while (0)
 #define ANRAG_BM25(F, S)                                                   \
     do {                                                                   \
         if (small) ANRAG_BM25_T(F, S, kBm25ThreadsSmall);                  \
@@ -677,9 +696,16 @@ int launch_bm25_lists(anrag_index *idx, hipStream_t st, const int32_t *d_terms, 
         }
 #undef ANRAG_BM25
 #undef ANRAG_BM25_T
+#undef ANRAG_BM25_ATTR
         ANRAG_HIP(hipGetLastError());
     }
     return ANRAG_OK;
+}
+
+int launch_bm25_lists(anrag_index *idx, hipStream_t st, const int32_t *d_terms, int32_t n_terms, int32_t k,
+                      const uint32_t *d_allow_bits, double *d_scores_out, int set) {
+    return launch_bm25_lists_group(idx, st, &d_terms, &n_terms, 1, k, d_allow_bits, d_scores_out ? &d_scores_out : nullptr,
+                                   &set);
 }
 
 int launch_bm25(anrag_index *idx, hipStream_t st, const int32_t *d_terms, int32_t n_terms, int32_t k,

@@ -245,6 +245,9 @@ int launch_dense_scan_group(anrag_index *idx, hipStream_t stream, const float *c
                             int64_t scores_stride = 0);
 int launch_bm25_lists(anrag_index *idx, hipStream_t st, const int32_t *d_terms, int32_t n_terms, int32_t k,
                       const uint32_t *d_allow_bits, double *d_scores_out, int set);
+int launch_bm25_lists_group(anrag_index *idx, hipStream_t st, const int32_t *const *d_terms, const int32_t *n_terms,
+                            int32_t n_queries, int32_t k, const uint32_t *d_allow_bits, double *const *d_scores_out,
+                            const int *sets);
 // Tail of a query, ONE launch (tail.hip): merge the dense block lists of set `set` and/or the BM25 partition
 // lists into per-modality top-k, then either write both lists (kTailCandidates: d_out[0..k) dense,
 // [k..2k) BM25; with one modality only its k records at d_out[0..k)) or fuse them (kTailFuse: WRRF + top_n).
@@ -254,6 +257,10 @@ enum TailMode { kTailFuse = 0, kTailCandidates = 1, kTailCandidates2k = 2 };
 int launch_tail(anrag_index *idx, hipStream_t st, int set, bool use_dense, bool use_bm25, int32_t k, TailMode mode,
                 double w_dense, double w_bm25, double wrrf_k, int32_t top_n, anrag_candidate *d_out,
                 int32_t *d_count);
+// ... for the n <= kScanGroupMax queries of a group in ONE launch (a workgroup per query)
+int launch_tail_group(anrag_index *idx, hipStream_t st, const int *sets, bool use_dense, const bool *use_bm25, int32_t n,
+                      int32_t k, TailMode mode, double w_dense, double w_bm25, double wrrf_k, int32_t top_n,
+                      anrag_candidate *const *d_out, int32_t *const *d_count);
 // K1 + tail on one stream (set 0)
 int launch_dense_topk(anrag_index *idx, hipStream_t stream, const float *d_query, int32_t k,
                       const uint32_t *d_allow_bits, anrag_candidate *d_out, float *d_scores_out);

@@ -682,12 +682,23 @@ extern "C" int anrag_rank_batch(const anrag_rank_leg *legs, int32_t n_legs, int3
                 }
                 ANRAG_HIP(hipMemcpyAsync(ld[l].seg_k, h_segk.data(), (size_t)c * 4, hipMemcpyHostToDevice, st));
                 ANRAG_HIP(hipStreamSynchronize(st));  // h_segk is reused
-                for (int32_t q = 0; q < c; ++q) {
-                    const int32_t n_terms = (int32_t)(g.term_offsets[q0 + q + 1] - g.term_offsets[q0 + q]);
-                    if (n_terms == 0) continue;
-                    if ((rc = launch_bm25_lists(ix, st, ld[l].terms + (g.term_offsets[q0 + q] - t0), n_terms, 0, ld[l].allow,
-                                                tile + (int64_t)q * ld[l].stride, 0)))
-                        return rc;
+                {  // K3 in its score-writing form, up to 8 queries per launch
+                    const int32_t *bt[kScanGroupMax];
+                    int32_t bn[kScanGroupMax];
+                    double *bo[kScanGroupMax];
+                    int nb = 0;
+                    for (int32_t q = 0; q <= c; ++q) {
+                        const int32_t n_terms = q < c ? (int32_t)(g.term_offsets[q0 + q + 1] - g.term_offsets[q0 + q]) : 0;
+                        if (q < c && n_terms > 0) {
+                            bt[nb] = ld[l].terms + (g.term_offsets[q0 + q] - t0);
+                            bn[nb] = n_terms;
+                            bo[nb++] = tile + (int64_t)q * ld[l].stride;
+                        }
+                        if (nb == kScanGroupMax || (q == c && nb > 0)) {
+                            if ((rc = launch_bm25_lists_group(ix, st, bt, bn, nb, 0, ld[l].allow, bo, nullptr))) return rc;
+                            nb = 0;
+                        }
+                    }
                 }
                 if ((rc = launch_seg_sort<double, false>(device, st, c, tile, ld[l].stride, nullptr, 0, (int32_t)leg_rows[l],
                                                          leg_k[l], ld[l].seg_k, ld[l].rows, ld[l].row_keys, leg_k[l],

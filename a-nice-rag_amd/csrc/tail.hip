@@ -18,24 +18,48 @@ namespace anrag {
 
 constexpr int kTailThreads = 512;  // 8 waves: 4 per modality
 
-struct TailArgs {
+// one workgroup per query of a group (blockIdx.x): the tails of the queries that shared a scan / K3 launch share one too
+struct TailQuery {
     const float *d_score;     // dense block lists
     const uint32_t *d_row;
-    int32_t n_dense;          // 0 = no dense leg
-    const int64_t *dense_doc;
-    int64_t dense_base;
     const double *b_score;    // BM25 partition lists
     const uint32_t *b_row;
+    int32_t n_dense;          // 0 = no dense leg
     int32_t n_bm25;           // 0 = no BM25 leg
+    anrag_candidate *out;
+    int32_t *count;
+};
+struct TailGroup {
+    TailQuery q[kScanGroupMax];
+    const int64_t *dense_doc;
+    int64_t dense_base;
     const int64_t *bm25_doc;
     int64_t bm25_base;
     int32_t k, mode, top_n;
     double w_dense, w_bm25, wrrf_k;
-    anrag_candidate *out;
-    int32_t *count;
+};
+struct TailArgs : TailQuery {
+    const int64_t *dense_doc;
+    int64_t dense_base;
+    const int64_t *bm25_doc;
+    int64_t bm25_base;
+    int32_t k, mode, top_n;
+    double w_dense, w_bm25, wrrf_k;
 };
 
-__global__ __launch_bounds__(kTailThreads) void query_tail_kernel(TailArgs a) {
+__global__ __launch_bounds__(kTailThreads) void query_tail_kernel(TailGroup grp) {
+    TailArgs a;
+    static_cast<TailQuery &>(a) = grp.q[blockIdx.x];
+    a.dense_doc = grp.dense_doc;
+    a.dense_base = grp.dense_base;
+    a.bm25_doc = grp.bm25_doc;
+    a.bm25_base = grp.bm25_base;
+    a.k = grp.k;
+    a.mode = grp.mode;
+    a.top_n = grp.top_n;
+    a.w_dense = grp.w_dense;
+    a.w_bm25 = grp.w_bm25;
+    a.wrrf_k = grp.wrrf_k;
     __shared__ float lf_s[4 * kListLen];
     __shared__ uint32_t lf_r[4 * kListLen];
     __shared__ double ld_s[4 * kListLen];
@@ -115,18 +139,25 @@ __global__ __launch_bounds__(kTailThreads) void query_tail_kernel(TailArgs a) {
     wrrf_in_block(s_id, s_c, s_score, s_owner, &s_distinct, m, a.top_n, a.out, a.count);
 }
 
-int launch_tail(anrag_index *idx, hipStream_t st, int set, bool use_dense, bool use_bm25, int32_t k, TailMode mode,
-                double w_dense, double w_bm25, double wrrf_k, int32_t top_n, anrag_candidate *d_out,
-                int32_t *d_count) {
-    TailArgs a;
-    a.d_score = idx->d_blk_score_f32 + (int64_t)set * kMaxScanLists * kListLen;
-    a.d_row = idx->d_blk_row_a + (int64_t)set * kMaxScanLists * kListLen;
-    a.n_dense = use_dense ? dense_scan_lists(idx) : 0;
+int launch_tail_group(anrag_index *idx, hipStream_t st, const int *sets, bool use_dense, const bool *use_bm25, int32_t n,
+                      int32_t k, TailMode mode, double w_dense, double w_bm25, double wrrf_k, int32_t top_n,
+                      anrag_candidate *const *d_out, int32_t *const *d_count) {
+    ANRAG_REQUIRE(n >= 1 && n <= kScanGroupMax, "tail group of %d queries", n);
+    TailGroup a;
+    for (int i = 0; i < kScanGroupMax; ++i) {
+        const int j = i < n ? i : 0;
+        TailQuery &q = a.q[i];
+        q.d_score = idx->d_blk_score_f32 + (int64_t)sets[j] * kMaxScanLists * kListLen;
+        q.d_row = idx->d_blk_row_a + (int64_t)sets[j] * kMaxScanLists * kListLen;
+        q.n_dense = use_dense ? dense_scan_lists(idx) : 0;
+        q.b_score = idx->d_blk_score_f64 + (int64_t)sets[j] * idx->n_parts * kListLen;
+        q.b_row = idx->d_blk_row_b + (int64_t)sets[j] * idx->n_parts * kListLen;
+        q.n_bm25 = use_bm25[j] ? idx->n_parts : 0;
+        q.out = d_out[j];
+        q.count = d_count ? d_count[j] : nullptr;
+    }
     a.dense_doc = idx->d_dense_doc;
     a.dense_base = idx->dense_doc_base;
-    a.b_score = idx->d_blk_score_f64 + (int64_t)set * idx->n_parts * kListLen;
-    a.b_row = idx->d_blk_row_b + (int64_t)set * idx->n_parts * kListLen;
-    a.n_bm25 = use_bm25 ? idx->n_parts : 0;
     a.bm25_doc = idx->d_bm25_doc;
     a.bm25_base = idx->bm25_doc_base;
     a.k = k;
@@ -135,12 +166,17 @@ int launch_tail(anrag_index *idx, hipStream_t st, int set, bool use_dense, bool 
     a.w_dense = w_dense;
     a.w_bm25 = w_bm25;
     a.wrrf_k = wrrf_k;
-    a.out = d_out;
-    a.count = d_count;
-    LaunchTimer t(idx, mode == kTailFuse ? ANRAG_KERNEL_WRRF : ANRAG_KERNEL_SELECT, st);
-    query_tail_kernel<<<1, kTailThreads, 0, st>>>(a);
+    LaunchTimer t(idx, mode == kTailFuse ? ANRAG_KERNEL_WRRF : ANRAG_KERNEL_SELECT, st, n);
+    query_tail_kernel<<<n, kTailThreads, 0, st>>>(a);
     ANRAG_HIP(hipGetLastError());
     return ANRAG_OK;
+}
+
+int launch_tail(anrag_index *idx, hipStream_t st, int set, bool use_dense, bool use_bm25, int32_t k, TailMode mode,
+                double w_dense, double w_bm25, double wrrf_k, int32_t top_n, anrag_candidate *d_out,
+                int32_t *d_count) {
+    return launch_tail_group(idx, st, &set, use_dense, &use_bm25, 1, k, mode, w_dense, w_bm25, wrrf_k, top_n, &d_out,
+                             d_count ? &d_count : nullptr);
 }
 
 }  // namespace anrag

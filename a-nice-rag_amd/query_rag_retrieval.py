@@ -249,19 +249,126 @@ class RetrievalEvaluationSystem:
         names = self._gid_tables[source_enum]["names"]
         return [names[g] for g in gids.tolist()]
 
+    # ------------------------------------------------------------------ query lists
+    def _rank_batch(self, queries: List[Dict], params: Dict, expected: Optional[List[str]] = None):
+        """The ids-only route for a LIST of queries as ONE `anrag_rank_batch` (rank_batch.hip): every active dense model
+        and BM25 scored into tiles, ranked and fused on the device -- what `retrieval_eval.py`'s k = 12,000 configurations
+        need 8,000 times over.  -> per-query id arrays (a list of int64 arrays), or with `expected` (one chunk id per
+        query) -> (ranks, totals): the 1-based rank of the expected id in each answer (-1: absent; retrieval_eval.py:75-82)
+        and the answers' lengths, without materialising the lists.  None = outside this route (the caller answers
+        query by query)."""
+        from .index import rank_batch
+
+        if not queries or not self.fused or params.get("return_docs"):
+            return None
+        similarity_k = params.get("similarity_k", 25)
+        common_sections_n = params.get("common_sections_n", 15)
+        info_source = params.get("info_source", "NICE")
+        model_weights = params.get("model_weights") or self.config.DEFAULT_MODEL_WEIGHTS.copy()
+        flt = params.get("filename_type_filter")
+        try:
+            for q in queries:
+                self._validate_inputs(q.get("query_embeddings"), similarity_k, common_sections_n, info_source)
+        except ValueError:
+            return None  # the per-query method raises where the reference raises
+        source_enum = InfoSource(info_source.lower())
+        embeddings_dict = self.embeddings_data.get(source_enum, {})
+        if not embeddings_dict:
+            return None
+        bm25_tuple = self.bm25_data.get(source_enum)
+        bm25, bm25_sections, bm25_section_ids = bm25_tuple if bm25_tuple else (None, [], [])
+        want_bm25 = bool(params.get("use_hybrid_search", False)) and bm25 is not None and model_weights.get("BM25", 0) > 0
+        if params.get("use_reranker", True) and any(q.get("query_text") for q in queries):
+            return None  # reranking materialises documents: per query
+        from .database_manager import DenseHandle
+        from .search_engine import _allow_of
+
+        active = None
+        dims = {key: DenseHandle.of(df).dim for key, df in embeddings_dict.items() if df is not None and not df.empty}
+        for q in queries:
+            keys = [key for key, _, _ in self.config.DENSE_MODELS
+                    if embeddings_dict.get(key) is not None and not embeddings_dict[key].empty
+                    and model_weights.get(key, 0) > 0 and key in q["query_embeddings"]]
+            if active is not None and keys != active:
+                return None  # the queries of one call must share their legs
+            active = keys
+            for key in keys:
+                e = q["query_embeddings"][key]
+                if e.dtype != np.float32 or e.size != dims[key]:
+                    return None  # fp64 queries are scored in fp64 by the per-query path (search_engine.py:157)
+        se = self.search_engine
+        legs = []
+        for key in active:
+            df = embeddings_dict[key]
+            h = DenseHandle.of(df)
+            allow = _allow_of(h, "dense", flt) if flt else None
+            legs.append(dict(index=h.index, weight=model_weights.get(key, 1.0), allow=allow,
+                             queries=np.stack([q["query_embeddings"][key].reshape(-1) for q in queries]),
+                             doc_of_row=self._gids(source_enum, ("dense", id(df)), df["id"].tolist())))
+        if want_bm25:
+            from .preprocess_bm25 import preprocess_text
+
+            proxy = se._proxy(bm25, bm25_sections)
+            term_lists = []
+            for q in queries:
+                tokens = q.get("query_tokens")
+                if not tokens and q.get("query_text"):
+                    tokens = preprocess_text(q["query_text"], use_lemmatization=True)
+                term_lists.append(proxy.term_ids(tokens) if tokens else np.zeros(0, np.int32))
+            allow = _allow_of(proxy, "bm25", flt) if flt else None
+            legs.append(dict(index=proxy.index, weight=model_weights.get("BM25", 1.0), allow=allow, term_lists=term_lists,
+                             doc_of_row=self._gids(source_enum, ("bm25", id(bm25_section_ids)), bm25_section_ids)))
+        n = len(queries)
+        if not legs:
+            return ([np.zeros(0, np.int64)] * n) if expected is None else (np.full(n, -1, np.int32), np.zeros(n, np.int32))
+        table = self._gid_tables[source_enum]
+        id_space = len(table["names"])
+        wrrf_k = params.get("wrrf_k", 60)
+        if expected is not None:
+            exp = np.array([table["of"].get(e, -2) for e in expected], dtype=np.int64)  # -2: an id no frame holds
+            _, _, counts, ranks = rank_batch(legs, n, int(similarity_k), float(wrrf_k), int(common_sections_n),
+                                             id_space=id_space, expect=exp, want_ids=False)
+            return ranks, counts
+        ids, _, counts = rank_batch(legs, n, int(similarity_k), float(wrrf_k), int(common_sections_n), id_space=id_space)
+        return [ids[i, :c] for i, c in enumerate(counts.tolist())]
+
+    def _names_of(self, source_enum, gid_rows: List[np.ndarray]) -> List[List[str]]:
+        table = self._gid_tables[source_enum]
+        arr = table.get("names_arr")
+        if arr is None or len(arr) != len(table["names"]):
+            arr = table["names_arr"] = np.array(table["names"], dtype=object)
+        return [arr[g].tolist() for g in gid_rows]
+
     def retrieve_documents_batch(self, queries: List[Dict], **params) -> List[List[str]]:
         """`retrieve_documents` for a LIST of queries (no reference counterpart: retrieval_eval.py:51-84 loops).
         Each element of `queries` holds the per-query arguments (`query_embeddings`, and `query_tokens` and/or
         `query_text`); `params` are the remaining keyword arguments of `retrieve_documents`, shared by all.
         Element i of the result is exactly `retrieve_documents(**queries[i], **params)`: requests inside the fused
         route's envelope (one dense model + BM25, ids out, no rerank, similarity_k <= 64) go to the library as ONE
-        `anrag_hybrid_search_batch`, i.e. through the device pipeline with a single host sync; anything else is
-        answered by the per-query method."""
+        `anrag_hybrid_search_batch` (the device pipeline, a single host sync); other ids-only requests -- any number of
+        dense models, with or without BM25, similarity_k up to retrieval_eval's 12,000 -- as ONE `anrag_rank_batch`;
+        anything else (reranking, `return_docs`, float64 embeddings) is answered by the per-query method."""
         def one_by_one():
             return [self.retrieve_documents(**q, **params) for q in queries]
 
-        if not queries or not self.fused or params.get("return_docs") or not params.get("use_hybrid_search", False):
+        def ranked():
+            try:
+                rows = self._rank_batch(queries, params)
+            except Exception as e:
+                from ._native import AnragError
+
+                if isinstance(e, AnragError) and e.code in (-100, -5):
+                    raise
+                logger.info(f"Batched ranking not applicable, answering one by one: {e}")
+                rows = None
+            if rows is None:
+                return one_by_one()
+            return self._names_of(InfoSource(params.get("info_source", "NICE").lower()), rows)
+
+        if not queries or not self.fused or params.get("return_docs"):
             return one_by_one()
+        if not params.get("use_hybrid_search", False):
+            return ranked()
         similarity_k = params.get("similarity_k", 25)
         common_sections_n = params.get("common_sections_n", 15)
         info_source = params.get("info_source", "NICE")
@@ -274,11 +381,13 @@ class RetrievalEvaluationSystem:
         source_enum = InfoSource(info_source.lower())
         embeddings_dict = self.embeddings_data.get(source_enum, {})
         bm25_tuple = self.bm25_data.get(source_enum)
-        if not embeddings_dict or not bm25_tuple or similarity_k > 64:
+        if not embeddings_dict or not bm25_tuple:
             return one_by_one()
+        if similarity_k > 64:
+            return ranked()
         bm25, bm25_sections, bm25_section_ids = bm25_tuple
         if bm25 is None or model_weights.get("BM25", 0) <= 0:
-            return one_by_one()
+            return ranked()
         keys = None
         token_lists = []
         for q in queries:
@@ -286,7 +395,7 @@ class RetrievalEvaluationSystem:
                       if embeddings_dict.get(key) is not None and not embeddings_dict[key].empty
                       and model_weights.get(key, 0) > 0 and key in q["query_embeddings"]]
             if len(active) != 1 or (keys is not None and active[0] != keys):
-                return one_by_one()
+                return ranked()
             keys = active[0]
             if params.get("use_reranker", True) and q.get("query_text"):
                 return one_by_one()
@@ -296,7 +405,9 @@ class RetrievalEvaluationSystem:
 
                 tokens = preprocess_text(q["query_text"], use_lemmatization=True)
             if not tokens:
-                return one_by_one()
+                return ranked()
+            if np.asarray(q["query_embeddings"][keys]).dtype == np.float64:
+                return one_by_one()  # scored in fp64 by the per-query route
             token_lists.append(tokens)
         try:
             emb = np.stack([np.asarray(q["query_embeddings"][keys], dtype=np.float32).reshape(-1) for q in queries])
@@ -312,6 +423,22 @@ class RetrievalEvaluationSystem:
             logger.error(f"Batched retrieval failed, answering one by one: {e}")
             out = None
         return out if out is not None else one_by_one()
+
+    def rank_of_expected_batch(self, queries: List[Dict], expected_ids: List[str], **params):
+        """For each query the 1-based rank of `expected_ids[i]` in what `retrieve_documents(**queries[i], **params)`
+        returns (-1 if it is not there) and that list's length -- `RetrievalEvaluator.evaluate_query`'s search of the
+        returned list (retrieval_eval.py:75-82), computed where the list is (one `anrag_rank_batch`, nothing but two
+        integers per query crosses PCIe).  None when the request is outside the batched ranking (the caller then asks
+        for the lists)."""
+        try:
+            return self._rank_batch(queries, params, expected=list(expected_ids))
+        except Exception as e:
+            from ._native import AnragError
+
+            if isinstance(e, AnragError) and e.code in (-100, -5):
+                raise
+            logger.info(f"Batched ranking not applicable: {e}")
+            return None
 
     def _section_dict(self, source_enum, bm25_sections):
         # the reference rebuilds this dict over all sections on EVERY query (:192); once is enough

@@ -216,6 +216,12 @@ int anrag_bm25_search(anrag_index *idx, const int32_t *term_ids, int32_t n_terms
  * ranks the all-zero score array, as anrag_bm25_search does. */
 int anrag_bm25_search_device(anrag_index *idx, const int32_t *d_term_ids, int32_t n_terms,
                              int32_t k, const uint32_t *d_allow_bits, anrag_candidate *d_out);
+/* The same for n_queries queries in one call: d_term_ids / d_out are HOST arrays of device pointers, n_terms a host
+ * array.  The queries run in groups of 8 per K3 launch (every query its own workgroups, the launch paid once per
+ * group); each takes a pipeline slot like a single call. */
+int anrag_bm25_search_group_device(anrag_index *idx, const int32_t *const *d_term_ids, const int32_t *n_terms,
+                                   int32_t n_queries, int32_t k, const uint32_t *d_allow_bits,
+                                   anrag_candidate *const *d_out);
 /* BM25Okapi.get_scores(query) itself: out host, n_docs fp64. */
 int anrag_bm25_scores(anrag_index *idx, const int32_t *term_ids, int32_t n_terms,
                       double *out_scores);

@@ -71,6 +71,40 @@ def test_retrieve_documents_matches_reference(world, fused):
         assert out == c["ids"], (fused, c["cfg"], c["tokens"])
 
 
+def test_retrieve_documents_batch_matches_reference(world):
+    """The reference's own `retrieve_documents` outputs (72 cases: 1-2 dense models, with / without BM25 and filter,
+    k 10 ... 300) through the LIST entry point: cases that share their keyword arguments are asked together, so the
+    k <= 64 hybrid cases take `anrag_hybrid_search_batch` and everything else `anrag_rank_batch` (full-ranking mode);
+    and the expected-id rank the evaluation harness asks for equals the position in the reference's list."""
+    import json
+
+    from oracle.make_golden import synth_query
+    from anrag.query_rag_retrieval import RetrievalEvaluationSystem
+
+    g, cfg, e1, e2, kept = world
+    system = RetrievalEvaluationSystem(cfg)
+    groups = {}
+    for c in g["cases"]:
+        groups.setdefault(json.dumps(c["cfg"], sort_keys=True), []).append(c)
+    routed = 0
+    for key, cases in groups.items():
+        params = json.loads(key)
+        asks = [{"query_embeddings": {"voyage-3-large": synth_query(e1, c["q1_seed"], c["target"]),
+                                      "text-embedding-3-large": synth_query(e2, c["q2_seed"], c["target"])},
+                 "query_tokens": c["tokens"]} for c in cases]
+        out = system.retrieve_documents_batch(asks, use_reranker=False, **params)
+        assert out == [c["ids"] for c in cases], params
+        expected = [c["ids"][len(c["ids"]) // 2] if c["ids"] else "no-such-id" for c in cases]
+        expected[0] = "no-such-id"
+        got = system.rank_of_expected_batch(asks, expected, use_reranker=False, **params)
+        if got is not None:
+            routed += 1
+            ranks, totals = got
+            for c, e, r, t in zip(cases, expected, ranks.tolist(), totals.tolist()):
+                assert t == len(c["ids"]) and r == (c["ids"].index(e) + 1 if e in c["ids"] else -1), (params, e)
+    assert routed == len(groups)  # every golden configuration is inside the batched ranking's envelope
+
+
 def test_database_manager_contract(world):
     from anrag.database_manager import ATTR, Bm25Proxy, DatabaseManager
     from anrag.config import InfoSource
