@@ -58,6 +58,8 @@ _SIGNATURES = {
     "anrag_index_destroy": [_p],
     "anrag_index_set_streams": [_p, _p, _p, _p],
     "anrag_index_sync": [_p],
+    "anrag_index_wait_stream": [_p, _p],
+    "anrag_index_signal_stream": [_p, _p],
     "anrag_dense_load": [_p, _p, _i64, _i32, _p, _p, _i64],
     "anrag_dense_search": [_p, _p, _i32, _i32, _p, _i32, _p, _p, _p],
     "anrag_dense_search_f64": [_p, _p, _i32, _p, _i32, _p, _p, _p],

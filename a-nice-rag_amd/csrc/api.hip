@@ -306,6 +306,7 @@ int anrag_index_destroy(anrag_index *idx) {
         if (idx->call_pin) (void)counted_host_free(idx->call_pin);
         if (idx->h_pinned) (void)counted_host_free(idx->h_pinned);
         for (hipEvent_t e : idx->event_pool) (void)hipEventDestroy(e);
+        if (idx->ev_order) (void)hipEventDestroy(idx->ev_order);
         for (int b = 0; b < kPipeSlots; ++b) {
             hipEvent_t evs[] = {idx->ev_scan[b], idx->ev_bm25[b], idx->ev_fused[b]};
             for (hipEvent_t ev : evs)
@@ -333,6 +334,26 @@ int anrag_index_set_streams(anrag_index *idx, void *primary, void *secondary, vo
 int anrag_index_sync(anrag_index *idx) {
     ANRAG_ENTER(idx);
     return sync_all(idx);
+}
+
+int anrag_index_wait_stream(anrag_index *idx, void *stream) {
+    ANRAG_ENTER(idx);
+    if (!idx->ev_order) ANRAG_HIP(hipEventCreateWithFlags(&idx->ev_order, hipEventDisableTiming));
+    ANRAG_HIP(hipEventRecord(idx->ev_order, (hipStream_t)stream));
+    for (hipStream_t s : {idx->primary, idx->secondary, idx->fusion})
+        if (s != (hipStream_t)stream) ANRAG_HIP(hipStreamWaitEvent(s, idx->ev_order, 0));
+    return ANRAG_OK;
+}
+
+int anrag_index_signal_stream(anrag_index *idx, void *stream) {
+    ANRAG_ENTER(idx);
+    if (!idx->ev_order) ANRAG_HIP(hipEventCreateWithFlags(&idx->ev_order, hipEventDisableTiming));
+    for (hipStream_t s : {idx->primary, idx->secondary, idx->fusion}) {
+        if (s == (hipStream_t)stream) continue;
+        ANRAG_HIP(hipEventRecord(idx->ev_order, s));  // a wait captures the event's state when it is enqueued:
+        ANRAG_HIP(hipStreamWaitEvent((hipStream_t)stream, idx->ev_order, 0));  // one event serves the three in turn
+    }
+    return ANRAG_OK;
 }
 
 // ------------------------------------------------------------------ dense
@@ -445,15 +466,13 @@ static int dense_search_batched_host(anrag_index *idx, hipStream_t st, const flo
     if ((rc = ensure_query_buffer(idx, (int64_t)256 * idx->dim))) return rc;
     std::vector<anrag_candidate> h((size_t)256 * k);
     std::vector<int32_t> flag(256);
-    anrag_candidate *d_out = nullptr;
-    int32_t *d_flag = nullptr;
-    ANRAG_HIP(counted_malloc(reinterpret_cast<void **>(&d_out), (size_t)256 * k * sizeof(anrag_candidate)));
-    hipError_t e = counted_malloc(reinterpret_cast<void **>(&d_flag), 256 * sizeof(int32_t));
-    if (e != hipSuccess) {
-        (void)counted_free(d_out);
-        set_error("hipMalloc failed: %s", hipGetErrorString(e));
-        return ANRAG_ERR_NOMEM;
-    }
+    // the pass's result records and flags: the index's grow-only call pool (no allocation in a steady-state loop)
+    if ((rc = ensure_pool(idx, idx->call_pool, (int64_t)256 * k * (int64_t)sizeof(anrag_candidate) + 256 * 4 + 1024)))
+        return rc;
+    Carver cv(idx->call_pool.p);
+    anrag_candidate *d_out = cv.take<anrag_candidate>((int64_t)256 * k);
+    int32_t *d_flag = cv.take<int32_t>(256);
+    hipError_t e = hipSuccess;
     rc = ANRAG_OK;
     for (int32_t q0 = 0; q0 < n_queries && rc == ANRAG_OK; q0 += 256) {
         const int32_t nq = std::min(256, n_queries - q0);
@@ -493,8 +512,6 @@ static int dense_search_batched_host(anrag_index *idx, hipStream_t st, const flo
             out_count[q0 + qi] = cnt;
         }
     }
-    (void)counted_free(d_out);
-    (void)counted_free(d_flag);
     return rc;
 }
 
@@ -1067,23 +1084,29 @@ int anrag_hybrid_search_batch(anrag_index *idx, const float *queries, const int3
     if ((rc = stage_allow(idx, P, allow_bm25, n_bm25_sources, idx->d_allow_b, reinterpret_cast<uint32_t *>(pin + 8192),
                           &d_ab)))
         return rc;
-    // one call's operands; freed before returning (a batch call is long: 0.44 ms per query at 1M rows)
+    // one call's operands and results: carved from the index's grow-only call pool, so a steady-state loop of list
+    // calls allocates nothing (hipMalloc / hipFree synchronise the whole device)
+    Carver measure(nullptr);
+    auto carve = [&](Carver &c, float *&q, int32_t *&t, anrag_candidate *&o, int32_t *&n) {
+        q = dense ? c.take<float>((int64_t)n_queries * idx->dim) : nullptr;
+        t = total_terms > 0 ? c.take<int32_t>(total_terms) : nullptr;
+        o = c.take<anrag_candidate>((int64_t)n_queries * top_n);
+        n = c.take<int32_t>(n_queries);
+    };
     float *d_q = nullptr;
     int32_t *d_t = nullptr, *d_cnt = nullptr;
     anrag_candidate *d_out = nullptr;
+    carve(measure, d_q, d_t, d_out, d_cnt);
+    if ((rc = ensure_pool(idx, idx->call_pool, measure.at))) return rc;
+    Carver cv(idx->call_pool.p);
+    carve(cv, d_q, d_t, d_out, d_cnt);
     std::vector<anrag_candidate> h_out;
     std::vector<int32_t> h_cnt;
     auto body = [&]() -> int {
-        if (dense) {
-            ANRAG_HIP(counted_malloc(reinterpret_cast<void **>(&d_q), (size_t)n_queries * idx->dim * sizeof(float)));
+        if (dense)
             ANRAG_HIP(hipMemcpyAsync(d_q, queries, (size_t)n_queries * idx->dim * sizeof(float), hipMemcpyHostToDevice, P));
-        }
-        if (total_terms > 0) {
-            ANRAG_HIP(counted_malloc(reinterpret_cast<void **>(&d_t), (size_t)total_terms * sizeof(int32_t)));
+        if (total_terms > 0)
             ANRAG_HIP(hipMemcpyAsync(d_t, term_ids, (size_t)total_terms * sizeof(int32_t), hipMemcpyHostToDevice, P));
-        }
-        ANRAG_HIP(counted_malloc(reinterpret_cast<void **>(&d_out), (size_t)n_queries * top_n * sizeof(anrag_candidate)));
-        ANRAG_HIP(counted_malloc(reinterpret_cast<void **>(&d_cnt), (size_t)n_queries * sizeof(int32_t)));
         ANRAG_HIP(hipMemsetAsync(d_cnt, 0, (size_t)n_queries * sizeof(int32_t), P));
         ANRAG_HIP(hipStreamSynchronize(P));  // the other streams read the staged operands
         for (int32_t q0 = 0; q0 < n_queries; q0 += kScanGroup) {  // one scan launch per group of queries
@@ -1105,10 +1128,10 @@ int anrag_hybrid_search_batch(anrag_index *idx, const float *queries, const int3
         return ANRAG_OK;
     };
     rc = body();
-    if (rc) (void)sync_all(idx);  // nothing may still read the operands when they are freed
-    for (void *ptr : {(void *)d_q, (void *)d_t, (void *)d_out, (void *)d_cnt})
-        if (ptr) (void)counted_free(ptr);
-    if (rc) return rc;
+    if (rc) {
+        (void)sync_all(idx);  // nothing may still read the pool when the next call carves it again
+        return rc;
+    }
     for (int32_t q = 0; q < n_queries; ++q) {
         const int32_t cnt = std::min(h_cnt[q], top_n);
         for (int32_t i = 0; i < top_n; ++i) {

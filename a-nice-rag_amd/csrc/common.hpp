@@ -86,6 +86,19 @@ struct DevicePool {
     int64_t bytes = 0;
 };
 
+// carve pieces of 256-byte granularity out of one block (base == nullptr: only measure)
+struct Carver {
+    char *base;
+    int64_t at = 0;
+    explicit Carver(char *b) : base(b) {}
+    template <typename T>
+    T *take(int64_t count) {
+        T *p = base ? reinterpret_cast<T *>(base + at) : nullptr;
+        at += (count * (int64_t)sizeof(T) + 255) / 256 * 256;
+        return p;
+    }
+};
+
 }  // namespace anrag
 
 // One GPU's shard.  Everything the kernels touch lives in HBM for the index's lifetime.
@@ -104,6 +117,7 @@ struct anrag_index {
     hipEvent_t ev_fused[anrag::kPipeSlots] = {};   // tail of the slot finished: its lists may be overwritten
     uint64_t hyb_seq = 0;
     bool hyb_outstanding = false;
+    hipEvent_t ev_order = nullptr;  // anrag_index_wait_stream / anrag_index_signal_stream
     // host-pointer hybrid queries (anrag_hybrid_search): per-slot staging, so that callers on several threads
     // overlap -- a caller holds the index lock while it enqueues, not while it waits for its result
     struct HostSlot {

@@ -348,20 +348,13 @@ void free_batched(anrag_index *idx) {
 }
 
 template <int QW>
-static int batched_attrs() {
+static int batched_attrs(int device) {  // per device, under a mutex (common.hpp: ensure_dynamic_lds)
     using Geo = BatchGeom<QW>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        ANRAG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&dense_batched_kernel<QW, true, false>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, Geo::kLdsBytes));
-        ANRAG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&dense_batched_kernel<QW, true, true>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, Geo::kLdsBytes));
-        ANRAG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&dense_batched_kernel<QW, false, false>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, Geo::kLdsBytes));
-        ANRAG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&dense_batched_kernel<QW, false, true>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, Geo::kLdsBytes));
-        attr_set = true;
-    }
+    for (const void *f : {reinterpret_cast<const void *>(&dense_batched_kernel<QW, true, false>),
+                          reinterpret_cast<const void *>(&dense_batched_kernel<QW, true, true>),
+                          reinterpret_cast<const void *>(&dense_batched_kernel<QW, false, false>),
+                          reinterpret_cast<const void *>(&dense_batched_kernel<QW, false, true>)})
+        if (int rc = ensure_dynamic_lds(device, f, Geo::kLdsBytes)) return rc;
     return ANRAG_OK;
 }
 
@@ -381,7 +374,7 @@ static int batched_passes(anrag_index *idx, hipStream_t st, int32_t nq, int32_t 
     using Geo = BatchGeom<QW>;
     using GeoS = BatchGeom<128>;
     int rc;
-    if ((rc = batched_attrs<QW>()) || (rc = batched_attrs<128>())) return rc;
+    if ((rc = batched_attrs<QW>(idx->device)) || (rc = batched_attrs<128>(idx->device))) return rc;
     const int64_t n = idx->n_rows;
     const int dim = idx->dim;
     const int n_qblocks = (nq + QW - 1) / QW;  // 1

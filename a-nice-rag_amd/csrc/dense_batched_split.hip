@@ -434,19 +434,15 @@ __global__ void batched_threshold_kernel(const float *, int64_t, int32_t, float 
 
 int batched_passes_split(anrag_index *idx, hipStream_t st, int32_t nq, int32_t k, int64_t n_sample, int64_t stride,
                          const uint32_t *allow, Cand32 *cand) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        ANRAG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&dense_batched_split_kernel<true, false>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, kSplitLdsBytes));
-        ANRAG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&dense_batched_split_kernel<true, true>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, kSplitLdsBytes));
-        for (const void *f : {reinterpret_cast<const void *>(&dense_batched_split_dma_kernel<false, 2>),
-                              reinterpret_cast<const void *>(&dense_batched_split_dma_kernel<true, 2>),
-                              reinterpret_cast<const void *>(&dense_batched_split_dma_kernel<false, 1>),
-                              reinterpret_cast<const void *>(&dense_batched_split_dma_kernel<true, 1>)})
-            ANRAG_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, kDmaLdsTotal));
-        attr_set = true;
-    }
+    // > 64 KB of dynamic LDS: asked for per device, under a mutex (common.hpp: ensure_dynamic_lds)
+    for (const void *f : {reinterpret_cast<const void *>(&dense_batched_split_kernel<true, false>),
+                          reinterpret_cast<const void *>(&dense_batched_split_kernel<true, true>)})
+        if (int rc = ensure_dynamic_lds(idx->device, f, kSplitLdsBytes)) return rc;
+    for (const void *f : {reinterpret_cast<const void *>(&dense_batched_split_dma_kernel<false, 2>),
+                          reinterpret_cast<const void *>(&dense_batched_split_dma_kernel<true, 2>),
+                          reinterpret_cast<const void *>(&dense_batched_split_dma_kernel<false, 1>),
+                          reinterpret_cast<const void *>(&dense_batched_split_dma_kernel<true, 1>)})
+        if (int rc = ensure_dynamic_lds(idx->device, f, kDmaLdsTotal)) return rc;
     const int64_t n = idx->n_rows;
     const int dim = idx->dim;
     const int64_t qelems = (int64_t)kBQ * dim;

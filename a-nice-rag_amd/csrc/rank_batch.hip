@@ -432,19 +432,6 @@ static int launch_seg_sort(int device, hipStream_t st, int32_t n_seg, const KEY 
     return ANRAG_OK;
 }
 
-// carve pieces of 256-byte granularity out of one block
-struct Carver {
-    char *base;
-    int64_t at = 0;
-    explicit Carver(char *b) : base(b) {}
-    template <typename T>
-    T *take(int64_t count) {
-        T *p = base ? reinterpret_cast<T *>(base + at) : nullptr;
-        at += (count * (int64_t)sizeof(T) + 255) / 256 * 256;
-        return p;
-    }
-};
-
 }  // namespace anrag
 
 using namespace anrag;

@@ -138,6 +138,17 @@ class Index:
     def sync(self) -> None:
         nat.check(self._lib.anrag_index_sync(self.handle))
 
+    def wait_stream(self, stream: int = 0) -> None:
+        """Order the index's streams after the work already enqueued on `stream` (e.g.
+        torch.cuda.current_stream().cuda_stream): inputs produced and outputs allocated / filled there are safe to hand
+        to the *_device entry points, no host sync."""
+        nat.check(self._lib.anrag_index_wait_stream(self.handle, stream or None))
+
+    def signal_stream(self, stream: int = 0) -> None:
+        """Order `stream` after everything the index has enqueued: the caller's framework may read the results on
+        that stream without a host sync."""
+        nat.check(self._lib.anrag_index_signal_stream(self.handle, stream or None))
+
     # ------------------------------------------------------------------ dense
     def dense_load(self, embeddings, source_id=None, doc_id=None, doc_id_base: int = 0) -> None:
         """Upload the row-major fp32 corpus matrix (numpy array, or an (address, n, d) tuple of a

@@ -148,7 +148,8 @@ class RetrievalEvaluationSystem:
                 if not results.empty:
                     ranked_lists.append((results["id"].tolist(), key))
                     for rec in results.to_dict("records"):
-                        all_results.setdefault(rec["id"], rec)
+                        all_results.setdefault(rec["id"], rec)  # an id a LATER model returns again keeps the first
+                                                                # model's record (:242-245, :272-275, :293-294)
 
             if want_bm25:
                 bm25_ranked = None

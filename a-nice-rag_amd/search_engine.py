@@ -356,6 +356,11 @@ class SearchEngine:
         q = np.asarray(query_embedding)
         if q.ndim == 2 and q.shape[0] != 1:
             return None
+        if q.dtype == np.float64:
+            # the text path's embedding (:157): the reference scores it in fp64 (:129) and so does the method-by-method
+            # route (`anrag_dense_search_f64`); the fused call scores fp32 -- inside 1e-4, but near-ties could order
+            # differently between the two routes of ONE retrieve_documents call: declined, both routes score alike
+            return None
         proxy = self._proxy(bm25, bm25_sections)
         pair = FusedPair.of(df, proxy, bm25_section_ids)
         ad = ab = None

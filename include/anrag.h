@@ -107,6 +107,19 @@ int anrag_index_destroy(anrag_index *idx);
 int anrag_index_set_streams(anrag_index *idx, void *primary, void *secondary, void *fusion);
 /* Block until everything enqueued on the index's streams has finished. */
 int anrag_index_sync(anrag_index *idx);
+/* Stream ordering WITHOUT a host sync, for callers that keep their own streams (a framework's current stream):
+ *   anrag_index_wait_stream    everything the index enqueues from now on runs after the work ALREADY enqueued on
+ *                              `stream` (hipStream_t as void*, NULL = the null stream): call it after producing
+ *                              device inputs AND after allocating / filling device outputs on that stream (a
+ *                              framework's zero fill of a fresh tensor would otherwise race the library's answer),
+ *                              before the *_device call;
+ *   anrag_index_signal_stream  everything enqueued on `stream` from now on runs after the work already enqueued
+ *                              on the index's three streams: call it after the *_device call(s), before the
+ *                              framework reads the results on its stream.
+ * The default recipe of INTEGRATION.md ("Streams"); anrag_index_set_streams is the alternative that removes the
+ * index's own streams altogether. */
+int anrag_index_wait_stream(anrag_index *idx, void *stream);
+int anrag_index_signal_stream(anrag_index *idx, void *stream);
 
 /* ------------------------------------------------------------------ dense: load
  * The upload point that replaces per-row np.frombuffer + DataFrame

@@ -21,6 +21,11 @@ Vectors:
              and a BM25 pickle (bm25_search.py:82-93) that holds the ORACLE's
              BM25Okapi restatement (rank_bm25 is not installed): G4 therefore pins
              the glue, the filters, the selection and the fusion -- not BM25 scores.
+             `ref_end_to_end_docs.json`: the same call with `return_docs=True` and / or the reranker on
+             (query_rag_retrieval.py:372-407) -- the documents handed back (id, document, source, similarity,
+             rerank_score, key set; for an id two dense models return, the FIRST model's record stands, :272-275) and the
+             hand-off to `vo.rerank` (search_engine.py:161-203), answered by a deterministic stand-in client
+             (`StubVoyageClient`, shared with the tests: the hosted cross-encoder itself is out of scope).
   G5 metrics retrieval_eval.calculate_metrics                (retrieval_eval.py:90-116)
 """
 from __future__ import annotations
@@ -43,14 +48,26 @@ sys.path.insert(0, REPO)
 sys.dont_write_bytecode = True  # never leave .pyc behind in the read-only reference
 
 
+class StubVoyageClient:
+    """Stand-in for `voyageai.Client` (constructed at query_rag_retrieval.py:29).  `rerank` has the hosted API's shape
+    (search_engine.py:178-193 reads `.results[i].index` / `.relevance_score`) and a deterministic rule: relevance =
+    query words found in the text + 1 / (1 + text length), best first, ties by position, cut to top_k."""
+
+    def __init__(self, *a, **k):
+        self.calls = []
+
+    def rerank(self, query, documents, model, top_k, truncation=True):
+        words = set(query.lower().split())
+        scores = [float(sum(1 for w in d.lower().split() if w in words)) + 1.0 / (1.0 + len(d)) for d in documents]
+        order = sorted(range(len(documents)), key=lambda i: (-scores[i], i))[:top_k]
+        self.calls.append(dict(query=query, n_documents=len(documents), model=model, top_k=top_k))
+        return types.SimpleNamespace(
+            results=[types.SimpleNamespace(index=i, relevance_score=scores[i]) for i in order])
+
+
 def _plant_stubs():
     v = types.ModuleType("voyageai")
-
-    class Client:  # constructed at query_rag_retrieval.py:29; never called afterwards
-        def __init__(self, *a, **k):
-            pass
-
-    v.Client = Client
+    v.Client = StubVoyageClient
     sys.modules["voyageai"] = v
     p = types.ModuleType("processing")
     p.__path__ = []
@@ -311,7 +328,69 @@ def g4_end_to_end():
             cases.append(dict(target=target, q1_seed=400 + qi, q2_seed=500 + qi, tokens=toks, cfg=cfg, ids=list(out)))
     corpus = dict(n=n, d=d, chunk_seed=300, e1_seed=301, e2_seed=302,
                   chunks=[dict(id=c["id"], source=c["source"], tokens=c["tokens"]) for c in chunks])
-    return dict(corpus=corpus, cases=cases)
+
+    # ---- documents out / reranker on (query_rag_retrieval.py:372-407); same corpus, same system
+    def doc_record(doc):
+        rec = dict(id=doc["id"], document=doc["document"], source=doc["source"], similarity=float(doc["similarity"]),
+                   keys=sorted(doc.keys()))
+        if "rerank_score" in doc:
+            rec["rerank_score"] = float(doc["rerank_score"])
+        if "embedding" in doc:  # which model's row this record is: the first value of its embedding
+            rec["embedding0"] = float(np.asarray(doc["embedding"]).reshape(-1)[0])
+        return rec
+
+    from oracle import ref_retrieval
+
+    contents = [c["content"] for c in chunks]
+    o_dense = {"voyage-3-large": ref_retrieval.DenseCorpus([c["id"] for c in chunks], [c["source"] for c in chunks], e1, contents),
+               "text-embedding-3-large": ref_retrieval.DenseCorpus([c["id"] for c in chunks], [c["source"] for c in chunks], e2,
+                                                                   contents)}
+    o_bm = ref_retrieval.Bm25Corpus(bm25, [c["id"] for c in kept], [c["source"] for c in kept], [c["content"] for c in kept])
+    doc_cases = []
+    for qi in range(6):
+        target = int(rng.integers(0, n))
+        q1 = synth_query(e1, 600 + qi, target)
+        q2 = synth_query(e2, 700 + qi, target)
+        toks = [str(t) for t in rng.choice(chunks[target]["tokens"] or VOCAB, size=int(rng.integers(2, 6)))]
+        text = " ".join(toks[:3])
+        for cfg in (
+            dict(similarity_k=25, common_sections_n=15, use_hybrid_search=True, wrrf_k=40, return_docs=True,
+                 use_reranker=False, model_weights={"voyage-3-large": 5.0, "BM25": 1.0}, filename_type_filter=None),
+            dict(similarity_k=25, common_sections_n=15, use_hybrid_search=True, wrrf_k=40, return_docs=True,
+                 use_reranker=True, reranker_model="rerank-2-lite", reranker_top_k=5,
+                 model_weights={"voyage-3-large": 5.0, "BM25": 1.0}, filename_type_filter="CG,NG"),
+            dict(similarity_k=25, common_sections_n=15, use_hybrid_search=True, wrrf_k=40, return_docs=False,
+                 use_reranker=True, reranker_model="rerank-2", reranker_top_k=10,
+                 model_weights={"voyage-3-large": 5.0, "BM25": 1.0}, filename_type_filter="CG,NG"),
+            dict(similarity_k=12, common_sections_n=20, use_hybrid_search=False, wrrf_k=60, return_docs=True,
+                 use_reranker=False, model_weights={"voyage-3-large": 2.0, "text-embedding-3-large": 1.0},
+                 filename_type_filter=None),
+            dict(similarity_k=300, common_sections_n=40, use_hybrid_search=True, wrrf_k=40, return_docs=True,
+                 use_reranker=True, reranker_model="rerank-2", reranker_top_k=None,
+                 model_weights={"voyage-3-large": 1.0, "text-embedding-3-large": 1.0, "BM25": 3.0},
+                 filename_type_filter="NG"),
+            dict(similarity_k=5, common_sections_n=1, use_hybrid_search=True, wrrf_k=40, return_docs=True,
+                 use_reranker=True, reranker_model="rerank-2", reranker_top_k=3,  # one document: no rerank (:383)
+                 model_weights={"voyage-3-large": 5.0, "BM25": 1.0}, filename_type_filter=None),
+        ):
+            system.voyage_client.calls.clear()
+            out = system.retrieve_documents(
+                query_embeddings={"voyage-3-large": q1, "text-embedding-3-large": q2},
+                query_text=text, query_tokens=toks, **cfg)
+            # does this answer depend on how numpy happened to order EQUAL scores at a cut (argpartition / argsort
+            # leave that unspecified, search_engine.py:83-87, :236-243)?  The build's rule is (score desc, row asc): where
+            # the oracle's canonical reading returns other ids than the reference did, the case is marked and the tests
+            # hold the device to the canonical reading there ("Tie rule").
+            canon = ref_retrieval.retrieve_docs(
+                o_dense, o_bm, {"voyage-3-large": q1, "text-embedding-3-large": q2}, text, toks,
+                rerank_client=StubVoyageClient(), canonical=True, **cfg)
+            canon_ids = [d["id"] for d in canon] if cfg["return_docs"] else list(canon)
+            ref_ids = [d["id"] for d in out] if cfg["return_docs"] else list(out)
+            doc_cases.append(dict(
+                target=target, q1_seed=600 + qi, q2_seed=700 + qi, tokens=toks, text=text, cfg=cfg,
+                out=[doc_record(d) for d in out] if cfg["return_docs"] else list(out),
+                rerank_calls=list(system.voyage_client.calls), tie_free=bool(canon_ids == ref_ids)))
+    return dict(corpus=corpus, cases=cases), dict(cases=doc_cases)
 
 
 # ----------------------------------------------------------------------------- G5
@@ -337,11 +416,13 @@ def main():
 
     se = search_engine.SearchEngine(None, None)
     os.makedirs(OUT, exist_ok=True)
+    e2e, e2e_docs = g4_end_to_end()
     blobs = {
         "ref_dense.json": g1_dense(se),
         "ref_wrrf.json": g2_wrrf(se),
         "ref_bm25_selection.json": g3_bm25_selection(se),
-        "ref_end_to_end.json": g4_end_to_end(),
+        "ref_end_to_end.json": e2e,
+        "ref_end_to_end_docs.json": e2e_docs,
         "ref_metrics.json": g5_metrics(),
     }
     for name, data in blobs.items():

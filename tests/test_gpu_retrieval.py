@@ -105,6 +105,92 @@ def test_retrieve_documents_batch_matches_reference(world):
     assert routed == len(groups)  # every golden configuration is inside the batched ranking's envelope
 
 
+def test_return_docs_and_rerank_handoff_match_reference(world):
+    """query_rag_retrieval.py:372-407: `return_docs=True` hands back the records themselves (for an id two dense models
+    return, the FIRST model's record: later models' rows are filtered by `existing_ids`, :272-275; BM25-only sections
+    carry four keys and similarity 0.0, :336-350), and with `use_reranker` the fused documents go through `vo.rerank`
+    -- here the deterministic stand-in client the golden vectors were generated with."""
+    from oracle.make_golden import StubVoyageClient, synth_query
+    from anrag.query_rag_retrieval import RetrievalEvaluationSystem
+
+    g, cfg, e1, e2, kept = world
+    from oracle import ref_retrieval
+    from oracle.ref_bm25 import BM25Okapi
+
+    client = StubVoyageClient()
+    system = RetrievalEvaluationSystem(cfg, voyage_client=client)
+    chunks = g["corpus"]["chunks"]
+    ids, sources = [c["id"] for c in chunks], [c["source"] for c in chunks]
+    contents = [" ".join(c["tokens"]) or "-" for c in chunks]
+    o_dense = {"voyage-3-large": ref_retrieval.DenseCorpus(ids, sources, e1, contents),
+               "text-embedding-3-large": ref_retrieval.DenseCorpus(ids, sources, e2, contents)}
+    o_bm = ref_retrieval.Bm25Corpus(BM25Okapi([c["tokens"] for c in kept], k1=1.7, b=0.83, epsilon=0.05),
+                                    [c["id"] for c in kept], [c["source"] for c in kept],
+                                    [" ".join(c["tokens"]) for c in kept])
+    seen_rerank = tied = 0
+    for c in load_golden("ref_end_to_end_docs.json")["cases"]:
+        q = {"voyage-3-large": synth_query(e1, c["q1_seed"], c["target"]),
+             "text-embedding-3-large": synth_query(e2, c["q2_seed"], c["target"])}
+        client.calls.clear()
+        out = system.retrieve_documents(query_embeddings=q, query_text=c["text"], query_tokens=c["tokens"], **c["cfg"])
+        assert client.calls == c["rerank_calls"], c["cfg"]
+        seen_rerank += len(client.calls)
+        if not c["tie_free"]:
+            # the reference's answer here depends on how numpy ordered EQUAL scores at a cut (unspecified); the build's
+            # rule is (score desc, row asc): the device must equal the oracle's canonical reading (DESIGN.md, "Tie rule")
+            tied += 1
+            want = ref_retrieval.retrieve_docs(o_dense, o_bm, q, c["text"], c["tokens"], rerank_client=StubVoyageClient(),
+                                               canonical=True, **c["cfg"])
+            got_ids = [d["id"] for d in out] if c["cfg"]["return_docs"] else out
+            assert got_ids == ([d["id"] for d in want] if c["cfg"]["return_docs"] else want), c["cfg"]
+            continue
+        if not c["cfg"]["return_docs"]:
+            assert out == c["out"], c["cfg"]
+            continue
+        assert [d["id"] for d in out] == [d["id"] for d in c["out"]], c["cfg"]
+        for got, want in zip(out, c["out"]):
+            assert sorted(got.keys()) == want["keys"], (got.keys(), want["keys"])
+            assert got["document"] == want["document"] and got["source"] == want["source"]
+            assert abs(float(got["similarity"]) - want["similarity"]) <= 1e-4
+            assert got.get("rerank_score") == want.get("rerank_score")
+            if "embedding0" in want:
+                assert float(np.asarray(got["embedding"]).reshape(-1)[0]) == want["embedding0"]
+    assert seen_rerank >= 12 and tied <= 4  # nearly every golden case is free of ties at a cut
+
+
+def test_fp64_query_scores_alike_on_both_routes(world):
+    """The text path hands `retrieve_documents` a float64 embedding (search_engine.py:157: the API's list through
+    np.array); the reference scores it in fp64 (:129).  Both routes of the host layer must do the same -- the fused
+    single-call route declines fp64 queries -- and agree with the oracle's fp64 ranking."""
+    from oracle import ref_retrieval
+    from oracle.make_golden import synth_query
+    from oracle.ref_bm25 import BM25Okapi
+    from anrag.query_rag_retrieval import RetrievalEvaluationSystem
+
+    g, cfg, e1, e2, kept = world
+    chunks = g["corpus"]["chunks"]
+    ids, sources = [c["id"] for c in chunks], [c["source"] for c in chunks]
+    bm = ref_retrieval.Bm25Corpus(BM25Okapi([c["tokens"] for c in kept], k1=1.7, b=0.83, epsilon=0.05),
+                                  [c["id"] for c in kept], [c["source"] for c in kept])
+    dense = {"voyage-3-large": ref_retrieval.DenseCorpus(ids, sources, e1)}
+    fused, plain = RetrievalEvaluationSystem(cfg, fused=True), RetrievalEvaluationSystem(cfg, fused=False)
+    rng = np.random.default_rng(31)
+    for i in range(12):
+        target = int(rng.integers(0, len(chunks)))
+        q64 = synth_query(e1, 900 + i, target).astype(np.float64) + rng.standard_normal(e1.shape[1]) * 1e-9
+        toks = chunks[target]["tokens"][:3] or ["asthma"]
+        kw = dict(query_tokens=toks, similarity_k=25, common_sections_n=15, use_hybrid_search=True, wrrf_k=40,
+                  model_weights={"voyage-3-large": 5.0, "BM25": 1.0}, filename_type_filter=None, use_reranker=False)
+        a = fused.retrieve_documents(query_embeddings={"voyage-3-large": q64}, **kw)
+        b = plain.retrieve_documents(query_embeddings={"voyage-3-large": q64}, **kw)
+        want = ref_retrieval.retrieve_ids(dense, bm, {"voyage-3-large": q64}, toks, 25, 15,
+                                          {"voyage-3-large": 5.0, "BM25": 1.0}, None, True, 40, canonical=True)
+        assert a == b == want, i
+        lists = fused.retrieve_documents_batch([{"query_embeddings": {"voyage-3-large": q64}, "query_tokens": toks}],
+                                               **{k: v for k, v in kw.items() if k != "query_tokens"})
+        assert lists == [want]
+
+
 def test_database_manager_contract(world):
     from anrag.database_manager import ATTR, Bm25Proxy, DatabaseManager
     from anrag.config import InfoSource

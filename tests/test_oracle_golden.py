@@ -111,6 +111,40 @@ def test_end_to_end_matches_reference(e2e):
         assert out == c["ids"], (c["cfg"], c["tokens"])
 
 
+def test_documents_and_rerank_handoff_match_reference(e2e):
+    """`return_docs=True` and the reranker hand-off (query_rag_retrieval.py:372-407): the reference's own outputs with a
+    deterministic stand-in for the hosted cross-encoder (oracle/make_golden.py: StubVoyageClient)."""
+    from oracle.make_golden import StubVoyageClient
+
+    g, dense, bm, e1, e2 = e2e
+    chunks = g["corpus"]["chunks"]
+    contents = [" ".join(c["tokens"]) or "-" for c in chunks]
+    kept = [c for c in chunks if c["tokens"]]
+    dense = {k: ref_retrieval.DenseCorpus(v.ids, v.sources, v.embeddings, contents) for k, v in dense.items()}
+    bm = ref_retrieval.Bm25Corpus(bm.bm25, bm.section_ids, bm.section_sources, [" ".join(c["tokens"]) for c in kept])
+    reranked = 0
+    for c in load_golden("ref_end_to_end_docs.json")["cases"]:
+        q = {"voyage-3-large": synth_query(e1, c["q1_seed"], c["target"]),
+             "text-embedding-3-large": synth_query(e2, c["q2_seed"], c["target"])}
+        client = StubVoyageClient()
+        out = ref_retrieval.retrieve_docs(dense, bm, q, c["text"], c["tokens"], rerank_client=client, **c["cfg"])
+        assert client.calls == c["rerank_calls"], c["cfg"]
+        reranked += len(client.calls)
+        if not c["cfg"]["return_docs"]:
+            assert out == c["out"], c["cfg"]
+            continue
+        assert [d["id"] for d in out] == [d["id"] for d in c["out"]], c["cfg"]
+        for got, want in zip(out, c["out"]):
+            assert got["document"] == want["document"] and got["source"] == want["source"]
+            assert abs(float(got["similarity"]) - want["similarity"]) <= 1e-6
+            assert got.get("rerank_score") == want.get("rerank_score")
+            if "embedding0" in want:  # which model's record stands (the first model's: :272-275)
+                assert got["embedding0"] == want["embedding0"]
+            else:
+                assert "embedding0" not in got
+    assert reranked >= 12
+
+
 def test_metrics_match_reference():
     for c in load_golden("ref_metrics.json"):
         m = ref_retrieval.calculate_metrics(c["results"])

@@ -80,8 +80,12 @@ def test_morphy_rules_and_exceptions():
     assert lem.lemmatize("knives") == "knife" or lem.lemmatize("knives") == "knif"  # ves -> f ("knif" unless known)
     assert lem.lemmatize("boxes") == "box"            # xes -> x
     assert lem.lemmatize("gas") == "ga"               # observed: WordNet's shortest-candidate quirk is kept
-    assert lem.lemmatize("tablets") == "tablet"       # unseen, no dictionary candidate: plain plural rule
-    assert lem.lemmatize("diabetes") == "diabete"     # ... which is a guess: the documented unpinned residue
+    # unseen word, no dictionary candidate: the plain plural rule is taken anyway.  PARITY UNPINNED: WordNet accepts a
+    # candidate only if it is one of its nouns ("tablets" -> "tablet", but "diabetes" stays "diabetes"); without its
+    # index (not available offline) rule 3 is a guess, so nothing here asserts WHICH lemma such a word gets -- only
+    # that the answer is the word itself or one of morphy's detachment candidates, and that the route is counted.
+    assert lem.lemmatize("tablets") in ("tablet", "tablets")
+    assert lem.lemmatize("diabetes") in ("diabetes", "diabete")
     assert lem.lemmatize("class") == "class" and lem.lemmatize("virus") == "virus" and lem.lemmatize("25s") == "25s"
     assert lem.counts["observed"] == 1 and lem.counts["rule"] >= 2 and lem.counts["unchanged"] >= 3
 
