@@ -909,22 +909,13 @@ static void free_host_slots(anrag_index *idx) {
         if (hs.done) (void)hipEventDestroy(hs.done);
         hs = anrag_index::HostSlot();
     }
-    idx->host_slot_dim = 0;
+    idx->host_ring.sized_for = 0;
 }
 
-static int ensure_host_slots(anrag_index *idx, std::unique_lock<std::mutex> &lock) {
-    const int32_t dim = idx->dim > 0 ? idx->dim : 1;
-    if (idx->host_slot_dim == dim) return ANRAG_OK;
-    // re-sizing: nobody may still be reading a slot
-    idx->slot_cv.wait(lock, [&] {
-        for (const auto &hs : idx->host_slot)
-            if (hs.busy) return false;
-        return true;
-    });
-    if (idx->host_slot_dim == dim) return ANRAG_OK;  // another caller did it while this one waited
+// (re)allocate the slots' staging for rows of `dim` floats: ONE pinned block and ONE device block, carved per slot:
+// query | terms | allow (dense) | allow (BM25) | result records | count.  Called by the ring when no slot is busy.
+static int alloc_host_slots(anrag_index *idx, int32_t dim) {
     free_host_slots(idx);
-    // ONE pinned block and ONE device block, carved per slot: query | terms | allow (dense) | allow (BM25) |
-    // result records | count
     const size_t qbytes = ((size_t)dim * sizeof(float) + 255) / 256 * 256;
     const size_t slot_bytes = qbytes + kSlotTerms + 2 * kSlotAllow + kSlotOut + 256;
     ANRAG_HIP(counted_host_malloc(reinterpret_cast<void **>(&idx->host_slots_h), slot_bytes * kPipeSlots, hipHostMallocDefault));
@@ -941,7 +932,6 @@ static int ensure_host_slots(anrag_index *idx, std::unique_lock<std::mutex> &loc
         hs.d_count = reinterpret_cast<int32_t *>(d + qbytes + kSlotTerms + 2 * kSlotAllow + kSlotOut);
         ANRAG_HIP(hipEventCreateWithFlags(&hs.done, hipEventDisableTiming));
     }
-    idx->host_slot_dim = dim;
     return ANRAG_OK;
 }
 
@@ -959,50 +949,48 @@ static int stage_allow_slot(hipStream_t st, const uint8_t *allow, int32_t n_sour
     return ANRAG_OK;
 }
 
-int anrag_hybrid_search(anrag_index *idx, const float *query, const int32_t *term_ids, int32_t n_terms,
-                        int32_t similarity_k, double w_dense, double w_bm25, double wrrf_k, int32_t top_n,
-                        const uint8_t *allow_dense, int32_t n_dense_sources, const uint8_t *allow_bm25,
-                        int32_t n_bm25_sources, int64_t *out_id, double *out_score, int32_t *out_count) {
-    ANRAG_REQUIRE(idx != nullptr, "index handle is NULL");
-    std::unique_lock<std::mutex> lock(idx->mu);
-    DeviceGuard guard(idx->device);
-    if (!guard.ok) {
-        set_error("hipSetDevice(%d) failed", idx->device);
-        return ANRAG_ERR_HIP;
+// The device side of one host-pointer hybrid query, as host_slots.hpp's Backend: the slot / sequence / waiter
+// bookkeeping itself lives there (GPU-free, exercised under ThreadSanitizer by tests/test_host_slots_tsan.py).
+namespace {
+struct HybridHostQuery {
+    anrag_index *idx;
+    const float *query;
+    const int32_t *term_ids;
+    int32_t n_terms, similarity_k;
+    double w_dense, w_bm25, wrrf_k;
+    int32_t top_n;
+    const uint8_t *allow_dense;
+    int32_t n_dense_sources;
+    const uint8_t *allow_bm25;
+    int32_t n_bm25_sources;
+    int64_t *out_id;
+    double *out_score;
+    int32_t *out_count;
+    bool dense = false;
+
+    size_t qbytes() const { return ((size_t)idx->host_ring.sized_for * sizeof(float) + 255) / 256 * 256; }
+
+    int prepare(std::unique_lock<std::mutex> &lock) {
+        ANRAG_REQUIRE(out_id && out_score && out_count, "NULL operand");
+        ANRAG_REQUIRE(similarity_k > 0 && similarity_k <= ANRAG_FUSED_K_MAX, "fused hybrid serves 1 <= similarity_k <= %d",
+                      ANRAG_FUSED_K_MAX);
+        ANRAG_REQUIRE(top_n > 0 && top_n <= 2 * ANRAG_FUSED_K_MAX, "top_n %d out of range", top_n);
+        ANRAG_REQUIRE(!(allow_dense && !idx->d_dense_src) && !(allow_bm25 && !idx->d_bm25_src),
+                      "a source filter needs source ids");
+        ANRAG_REQUIRE(n_terms >= 0 && n_terms <= 4096, "n_terms %d out of range [0, 4096]", n_terms);
+        ANRAG_REQUIRE(n_terms == 0 || term_ids != nullptr, "term_ids is NULL");
+        dense = idx->d_emb && w_dense > 0.0;
+        ANRAG_REQUIRE(!dense || query != nullptr, "query is NULL");
+        return idx->host_ring.ensure_size(lock, idx->dim > 0 ? idx->dim : 1,
+                                          [&](int32_t dim) { return alloc_host_slots(idx, dim); });
     }
-    ANRAG_REQUIRE(out_id && out_score && out_count, "NULL operand");
-    ANRAG_REQUIRE(similarity_k > 0 && similarity_k <= ANRAG_FUSED_K_MAX, "fused hybrid serves 1 <= similarity_k <= %d",
-                  ANRAG_FUSED_K_MAX);
-    ANRAG_REQUIRE(top_n > 0 && top_n <= 2 * ANRAG_FUSED_K_MAX, "top_n %d out of range", top_n);
-    ANRAG_REQUIRE(!(allow_dense && !idx->d_dense_src) && !(allow_bm25 && !idx->d_bm25_src),
-                  "a source filter needs source ids");
-    ANRAG_REQUIRE(n_terms >= 0 && n_terms <= 4096, "n_terms %d out of range [0, 4096]", n_terms);
-    ANRAG_REQUIRE(n_terms == 0 || term_ids != nullptr, "term_ids is NULL");
-    const bool dense = idx->d_emb && w_dense > 0.0;
-    ANRAG_REQUIRE(!dense || query != nullptr, "query is NULL");
-    int rc;
-    if ((rc = ensure_host_slots(idx, lock))) return rc;
-    // the slot hybrid_enqueue is about to use; its host block is free once the previous caller has copied out
-    int s;
-    for (;;) {
-        s = (int)(idx->hyb_seq % kPipeSlots);
-        if (!idx->host_slot[s].busy) break;
-        idx->slot_cv.wait(lock);
-    }
-    anrag_index::HostSlot &hs = idx->host_slot[s];
-    hs.busy = true;
-    auto release = [&](bool relock) {
-        if (relock) lock.lock();
-        hs.busy = false;
-        lock.unlock();
-        idx->slot_cv.notify_all();
-    };
-    hipStream_t P = idx->primary, S = idx->secondary;
-    const size_t qbytes = ((size_t)idx->host_slot_dim * sizeof(float) + 255) / 256 * 256;
-    char *h_terms = hs.h + qbytes, *h_aa = h_terms + kSlotTerms, *h_ab = h_aa + kSlotAllow, *h_out = h_ab + kSlotAllow;
-    char *h_cnt = h_out + kSlotOut;
-    const uint32_t *d_ad = nullptr, *d_ab = nullptr;
-    auto enqueue = [&]() -> int {
+    uint64_t next_seq() const { return idx->hyb_seq; }
+    int enqueue(int s) {
+        anrag_index::HostSlot &hs = idx->host_slot[s];
+        hipStream_t P = idx->primary, S = idx->secondary;
+        char *h_terms = hs.h + qbytes(), *h_aa = h_terms + kSlotTerms, *h_ab = h_aa + kSlotAllow, *h_out = h_ab + kSlotAllow;
+        char *h_cnt = h_out + kSlotOut;
+        const uint32_t *d_ad = nullptr, *d_ab = nullptr;
         int r;
         if ((r = stage_allow_slot(P, allow_dense, n_dense_sources, reinterpret_cast<uint32_t *>(h_aa), hs.d_allow_a, &d_ad)))
             return r;
@@ -1016,6 +1004,7 @@ int anrag_hybrid_search(anrag_index *idx, const float *query, const int32_t *ter
             memcpy(h_terms, term_ids, (size_t)n_terms * sizeof(int32_t));
             ANRAG_HIP(hipMemcpyAsync(hs.d_terms, h_terms, (size_t)n_terms * sizeof(int32_t), hipMemcpyHostToDevice, S));
         }
+        // takes pipeline slot hyb_seq % kPipeSlots == s and advances the sequence number
         if ((r = hybrid_enqueue(idx, kTailFuse, hs.d_query, hs.d_terms, n_terms, similarity_k, w_dense, w_bm25, wrrf_k,
                                 top_n, d_ad, d_ab, hs.d_out, hs.d_count)))
             return r;
@@ -1024,28 +1013,42 @@ int anrag_hybrid_search(anrag_index *idx, const float *query, const int32_t *ter
         ANRAG_HIP(hipMemcpyAsync(h_cnt, hs.d_count, sizeof(int32_t), hipMemcpyDeviceToHost, S));
         ANRAG_HIP(hipEventRecord(hs.done, S));
         return ANRAG_OK;
-    };
-    if ((rc = enqueue())) {
-        (void)sync_all(idx);  // nothing of this query may still touch the slot
-        release(false);
-        return rc;
     }
-    lock.unlock();
-    const hipError_t e = hipEventSynchronize(hs.done);
-    if (e != hipSuccess) {
-        set_error("hipEventSynchronize failed: %s", hipGetErrorString(e));
-        release(true);
+    void drain() { (void)sync_all(idx); }
+    int wait(int s) {
+        const hipError_t e = hipEventSynchronize(idx->host_slot[s].done);
+        if (e != hipSuccess) {
+            set_error("hipEventSynchronize failed: %s", hipGetErrorString(e));
+            return ANRAG_ERR_HIP;
+        }
+        return ANRAG_OK;
+    }
+    void fetch(int s) {
+        const char *h_out = idx->host_slot[s].h + qbytes() + kSlotTerms + 2 * kSlotAllow;
+        const anrag_candidate *h_cand = reinterpret_cast<const anrag_candidate *>(h_out);
+        const int32_t cnt = std::min(*reinterpret_cast<const int32_t *>(h_out + kSlotOut), top_n);
+        for (int32_t i = 0; i < cnt; ++i) {
+            out_id[i] = h_cand[i].doc;
+            out_score[i] = h_cand[i].score;
+        }
+        *out_count = cnt;
+    }
+};
+}  // namespace
+
+int anrag_hybrid_search(anrag_index *idx, const float *query, const int32_t *term_ids, int32_t n_terms,
+                        int32_t similarity_k, double w_dense, double w_bm25, double wrrf_k, int32_t top_n,
+                        const uint8_t *allow_dense, int32_t n_dense_sources, const uint8_t *allow_bm25,
+                        int32_t n_bm25_sources, int64_t *out_id, double *out_score, int32_t *out_count) {
+    ANRAG_REQUIRE(idx != nullptr, "index handle is NULL");
+    DeviceGuard guard(idx->device);
+    if (!guard.ok) {
+        set_error("hipSetDevice(%d) failed", idx->device);
         return ANRAG_ERR_HIP;
     }
-    const anrag_candidate *h_cand = reinterpret_cast<const anrag_candidate *>(h_out);
-    const int32_t cnt = std::min(*reinterpret_cast<const int32_t *>(h_cnt), top_n);
-    for (int32_t i = 0; i < cnt; ++i) {
-        out_id[i] = h_cand[i].doc;
-        out_score[i] = h_cand[i].score;
-    }
-    *out_count = cnt;
-    release(true);
-    return ANRAG_OK;
+    HybridHostQuery q{idx, query, term_ids, n_terms, similarity_k, w_dense, w_bm25, wrrf_k, top_n, allow_dense,
+                      n_dense_sources, allow_bm25, n_bm25_sources, out_id, out_score, out_count};
+    return host_slot_query(idx->mu, idx->host_ring, q);
 }
 
 // Many hybrid queries from host memory through the device pipeline: operands go up once, the queries are

@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "anrag.h"
+#include "host_slots.hpp"
 
 namespace anrag {
 
@@ -128,12 +129,10 @@ struct anrag_index {
         anrag_candidate *d_out = nullptr;
         int32_t *d_count = nullptr;
         hipEvent_t done = nullptr;
-        bool busy = false;
     };
     HostSlot host_slot[anrag::kPipeSlots];
     char *host_slots_h = nullptr, *host_slots_d = nullptr;  // the one pinned / one device block the slots carve
-    int32_t host_slot_dim = 0;        // dim the slots were sized for (0: not allocated)
-    std::condition_variable slot_cv;
+    anrag::HostSlotRing<anrag::kPipeSlots> host_ring;       // busy flags, waiters, the dimension the slots are sized for
 
     // ---- dense shard: row-major fp32, rows 16-byte aligned when dim % 4 == 0
     float *d_emb = nullptr;
