@@ -180,7 +180,30 @@ static int stage_allow(anrag_index *idx, hipStream_t st, const uint8_t *allow, i
     return ANRAG_OK;
 }
 
+// the merges still riding behind the lanes' last scans: launched on their own, each on its lane's stream
+static int flush_lanes(anrag_index *idx) {
+    if (!idx->lanes_active) return ANRAG_OK;
+    for (int l = 0; l < kScanLanesMax; ++l) {
+        anrag_index::ScanLane &ln = idx->lane[l];
+        if (!ln.pending) continue;
+        ln.pending = false;
+        int rc = launch_tail(idx, ln.st, ln.tail.set, /*dense*/ true, /*bm25*/ false, ln.tail.k, kTailCandidates, 0, 0, 0, 0,
+                             ln.tail.out, nullptr);
+        if (rc) return rc;
+    }
+    return ANRAG_OK;
+}
+
 int sync_all(anrag_index *idx) {
+    if (idx->lanes_active) {
+        int rc = flush_lanes(idx);
+        for (int l = 0; l < kScanLanesMax; ++l) {
+            ANRAG_HIP(hipStreamSynchronize(idx->lane[l].st));
+            idx->lane[l].count = 0;
+        }
+        idx->lanes_active = false;
+        if (rc) return rc;
+    }
     ANRAG_HIP(hipStreamSynchronize(idx->primary));
     ANRAG_HIP(hipStreamSynchronize(idx->secondary));
     ANRAG_HIP(hipStreamSynchronize(idx->fusion));
@@ -193,6 +216,13 @@ int settle_pipeline(anrag_index *idx) {
     if (!idx->hyb_outstanding) return ANRAG_OK;
     return sync_all(idx);
 }
+
+// lanes single dense queries rotate over (ANRAG_SCAN_LANES = 0, 1, 2 or 4 overrides; 0 = off).  100k x 768 at one query
+// per call: off 54.0, 1 lane 49.3, 2 lanes 46.4, 4 lanes 44.4 us per query (71 / 78 / 83 / 87 % of 8 TB/s); 9,609 x 384:
+// 21.2 -> 7.7 us per query.  A corpus whose pass dwarfs a launch boundary (> 1 GiB) takes ONE lane: several scans in
+// flight would only stretch each query's latency.
+constexpr int kScanLanesDefault = 4;
+constexpr int64_t kScanLanesMaxBytes = 1ll << 30;
 
 #define ANRAG_ENTER(idx)                                                   \
     ANRAG_REQUIRE((idx) != nullptr, "index handle is NULL");              \
@@ -252,6 +282,13 @@ int anrag_index_create(int device, anrag_index **out) {
     hipError_t e = hipStreamCreateWithFlags(&idx->own_primary, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&idx->own_secondary, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&idx->own_fusion, hipStreamNonBlocking);
+    for (auto &ln : idx->lane) {
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&ln.st, hipStreamNonBlocking);
+        for (auto &ev : ln.ev)
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+    }
+    idx->n_lanes = kScanLanesDefault;
+    if (const char *env = getenv("ANRAG_SCAN_LANES")) { const int v = atoi(env); idx->n_lanes = v <= 0 ? 0 : (v >= 4 ? 4 : (v == 3 ? 2 : v)); }
     for (int b = 0; b < kPipeSlots && e == hipSuccess; ++b) {
         e = hipEventCreateWithFlags(&idx->ev_scan[b], hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&idx->ev_bm25[b], hipEventDisableTiming);
@@ -286,9 +323,7 @@ int anrag_index_destroy(anrag_index *idx) {
     if (!idx) return ANRAG_OK;
     {
         DeviceGuard g(idx->device);
-        (void)hipStreamSynchronize(idx->primary);
-        (void)hipStreamSynchronize(idx->secondary);
-        (void)hipStreamSynchronize(idx->fusion);
+        (void)sync_all(idx);
         (void)drain_profile(idx);
         free_dense(idx);
         free_bm25(idx);
@@ -311,6 +346,11 @@ int anrag_index_destroy(anrag_index *idx) {
             hipEvent_t evs[] = {idx->ev_scan[b], idx->ev_bm25[b], idx->ev_fused[b]};
             for (hipEvent_t ev : evs)
                 if (ev) (void)hipEventDestroy(ev);
+        }
+        for (auto &ln : idx->lane) {
+            for (auto &ev : ln.ev)
+                if (ev) (void)hipEventDestroy(ev);
+            if (ln.st) (void)hipStreamDestroy(ln.st);
         }
         if (idx->own_fusion) (void)hipStreamDestroy(idx->own_fusion);
         if (idx->own_primary) (void)hipStreamDestroy(idx->own_primary);
@@ -342,12 +382,20 @@ int anrag_index_wait_stream(anrag_index *idx, void *stream) {
     ANRAG_HIP(hipEventRecord(idx->ev_order, (hipStream_t)stream));
     for (hipStream_t s : {idx->primary, idx->secondary, idx->fusion})
         if (s != (hipStream_t)stream) ANRAG_HIP(hipStreamWaitEvent(s, idx->ev_order, 0));
+    for (int l = 0; l < kScanLanesMax; ++l) ANRAG_HIP(hipStreamWaitEvent(idx->lane[l].st, idx->ev_order, 0));
     return ANRAG_OK;
 }
 
 int anrag_index_signal_stream(anrag_index *idx, void *stream) {
     ANRAG_ENTER(idx);
     if (!idx->ev_order) ANRAG_HIP(hipEventCreateWithFlags(&idx->ev_order, hipEventDisableTiming));
+    if (idx->lanes_active) {  // single dense queries: launch the merges still pending, then the lanes' streams count too
+        if (int rc = flush_lanes(idx)) return rc;
+        for (int l = 0; l < kScanLanesMax; ++l) {
+            ANRAG_HIP(hipEventRecord(idx->ev_order, idx->lane[l].st));
+            ANRAG_HIP(hipStreamWaitEvent((hipStream_t)stream, idx->ev_order, 0));
+        }
+    }
     for (hipStream_t s : {idx->primary, idx->secondary, idx->fusion}) {
         if (s == (hipStream_t)stream) continue;
         ANRAG_HIP(hipEventRecord(idx->ev_order, s));  // a wait captures the event's state when it is enqueued:
@@ -400,6 +448,43 @@ struct GroupQuery {
 static int hybrid_enqueue_group(anrag_index *idx, TailMode tail, const GroupQuery *q, int32_t n, int32_t k,
                                 double w_dense, double w_bm25, double wrrf_k, int32_t top_n,
                                 const uint32_t *d_allow_dense, const uint32_t *d_allow_bm25);
+// One dense-only query per call on the index's own streams: lane = query number mod n_lanes.  A lane owns
+// kPipeSlots / n_lanes list sets; the merge of its previous query rides in the scan launch of this one (DeferredTail),
+// so a lane's stream carries scans only -- no marker, no second stream -- and the lanes overlap.  Backpressure: an event
+// every quarter of a lane's sets; before a set is reused the call waits (on the HOST) for the launch that carried the
+// merge of its previous user.  The last merges are launched by whatever drains the index (sync_all).
+static int dense_single_enqueue(anrag_index *idx, const float *d_query, int32_t k, const uint32_t *d_allow,
+                                anrag_candidate *d_out) {
+    int rc;
+    if (!idx->lanes_active) {
+        if ((rc = settle_pipeline(idx))) return rc;  // the pipeline's queries own the same list sets
+        idx->lanes_active = true;
+        idx->lane_rr = 0;
+        idx->lanes_in_use = (int64_t)idx->n_rows * idx->dim * 4 > kScanLanesMaxBytes ? 1 : idx->n_lanes;
+    }
+    const int L = idx->lanes_in_use;
+    const int l = (int)(idx->lane_rr++ % (uint64_t)L);
+    anrag_index::ScanLane &ln = idx->lane[l];
+    const int per_lane = kPipeSlots / L, every = per_lane / 4;
+    const uint64_t ls = ln.count;
+    const int set = l * per_lane + (int)(ls % (uint64_t)per_lane);
+    if (ls >= (uint64_t)per_lane) {
+        // the set's previous user is lane query ls - per_lane; its merge rode in launch ls - per_lane + 1; event m
+        // was recorded behind launch (m + 1) * every - 1
+        const int64_t m = ((int64_t)ls - per_lane + 2 + every - 1) / every - 1;
+        hipEvent_t ev = ln.ev[m % 4];
+        if (hipEventQuery(ev) != hipSuccess) ANRAG_HIP(hipEventSynchronize(ev));
+    }
+    if ((rc = launch_dense_scan_group(idx, ln.st, &d_query, 1, k, d_allow, nullptr, &set, 0, ln.pending ? &ln.tail : nullptr)))
+        return rc;
+    ln.pending = true;
+    ln.tail = PendingTail{set, k, d_out};
+    ln.count = ls + 1;
+    if (ln.count % (uint64_t)every == 0) ANRAG_HIP(hipEventRecord(ln.ev[(ln.count / every - 1) % 4], ln.st));
+    idx->hyb_outstanding = true;
+    return ANRAG_OK;
+}
+
 constexpr int kScanGroup = 8;  // queries per scan launch when a call brings several (measured, queries per launch
                                // 1 -> 4 -> 8: 53.6 -> 47.1 -> 45.7 us per query at 100k rows, 64.0 -> 57.9 us at 125k
                                // rows for 4, nothing at 1M rows)
@@ -411,6 +496,10 @@ int anrag_dense_search_device(anrag_index *idx, const float *d_queries, int32_t 
     ANRAG_REQUIRE(d_queries && d_out, "NULL operand");
     ANRAG_REQUIRE(n_queries > 0, "n_queries must be positive");
     ANRAG_REQUIRE(k > 0 && k <= ANRAG_FUSED_K_MAX, "device path serves 1 <= k <= %d (got %d)", ANRAG_FUSED_K_MAX, k);
+    // one query per call on the index's own streams: the lane path (no marker and no merge launch per query)
+    if (n_queries == 1 && idx->n_lanes >= 1 && idx->primary == idx->own_primary && idx->fusion == idx->own_fusion &&
+        dense_scan_has_shape(idx) && (!d_allow_bits || idx->d_dense_src))
+        return dense_single_enqueue(idx, d_queries, k, d_allow_bits, d_out);
     // the dense-only member of the query pipeline: the queries of a call are scanned in groups -- one launch per
     // group, each query still its own pass over the matrix -- and every query's list merge runs on the fusion
     // stream under the following scans (results complete in fusion-stream order)
@@ -769,6 +858,8 @@ static int hybrid_enqueue_group(anrag_index *idx, TailMode tail, const GroupQuer
                                 double w_dense, double w_bm25, double wrrf_k, int32_t top_n,
                                 const uint32_t *d_allow_dense, const uint32_t *d_allow_bm25) {
     ANRAG_REQUIRE(n >= 1 && n <= kScanGroupMax && n <= kPipeSlots, "group of %d queries", n);
+    if (idx->lanes_active)  // single dense queries were using the list sets: drain them first (a rare change of mode)
+        if (int rc0 = sync_all(idx)) return rc0;
     // legs: a query vector asks for the dense leg (one scan launch serves the whole group: all or none); term ids
     // ask for the BM25 leg.  No term ids: BM25 is skipped as the reference skips it (search_engine.py:216-217) --
     // except for a BM25-only candidate query, which then ranks all-zero scores like anrag_bm25_search does.

@@ -23,6 +23,7 @@ constexpr int kScanGroupMax = 8;   // queries one scan launch can carry (dense_s
 constexpr int kPipeSlots = 32;     // queries in flight in the hybrid pipeline (list sets, events): four exchange
                                    // groups of 8, so a slow collective on the communication stream (which the tails
                                    // queue behind) does not stall the scans two groups later
+constexpr int kScanLanesMax = 4;     // scan streams that single dense queries rotate over (api.hip)
 constexpr int kMaxScanBlocks = 256;  // one per CU
 constexpr int kMaxScanLists = kMaxScanBlocks * kScanWaves;  // K1 leaves one sorted list per WAVE (the tail merges them)
 constexpr uint32_t kNoRow = 0xFFFFFFFFu;
@@ -87,6 +88,13 @@ struct DevicePool {
     int64_t bytes = 0;
 };
 
+// a single query's list merge that rides in the NEXT scan launch of its stream (dense_scan.hip: DeferredTail)
+struct PendingTail {
+    int set;              // list set the query's scan wrote
+    int32_t k;
+    anrag_candidate *out;
+};
+
 // carve pieces of 256-byte granularity out of one block (base == nullptr: only measure)
 struct Carver {
     char *base;
@@ -118,6 +126,22 @@ struct anrag_index {
     hipEvent_t ev_fused[anrag::kPipeSlots] = {};   // tail of the slot finished: its lists may be overwritten
     uint64_t hyb_seq = 0;
     bool hyb_outstanding = false;
+    // Dense-only queries submitted ONE per call (anrag_dense_search_device, n_queries == 1, the index's own streams):
+    // lanes of scans, each lane its own stream, consecutive queries on consecutive lanes.  A query's list merge rides in
+    // the next scan launch of its lane (no marker between the scans, no second stream to wake), the lanes' kernels
+    // overlap, so one query's launch boundary, ramp and drain are covered by the other lane's streaming.  api.hip.
+    struct ScanLane {
+        hipStream_t st = nullptr;
+        bool pending = false;         // a scan whose lists have not been merged yet
+        anrag::PendingTail tail{};
+        uint64_t count = 0;           // queries this lane has taken since the last drain
+        hipEvent_t ev[4] = {};        // backpressure: recorded every (slots per lane / 4) queries
+    };
+    ScanLane lane[anrag::kScanLanesMax];
+    int n_lanes = 1;                  // configured (ANRAG_SCAN_LANES)
+    int lanes_in_use = 1;             // ... and what the current run of single queries uses (1 for big corpora)
+    uint64_t lane_rr = 0;
+    bool lanes_active = false;
     hipEvent_t ev_order = nullptr;  // anrag_index_wait_stream / anrag_index_signal_stream
     // host-pointer hybrid queries (anrag_hybrid_search): per-slot staging, so that callers on several threads
     // overlap -- a caller holds the index lock while it enqueues, not while it waits for its result
@@ -253,9 +277,10 @@ int dense_scan_vgprs(const anrag_index *idx);  // registers of the scan kernel t
 // K1 alone: one sorted list per workgroup into block-list set `set` (or every score into d_scores_out, k = 0)
 int launch_dense_scan(anrag_index *idx, hipStream_t stream, const float *d_query, int32_t k,
                       const uint32_t *d_allow_bits, float *d_scores_out, int set);
+bool dense_scan_has_shape(const anrag_index *idx);  // a shaped (not the generic) scan kernel serves this dimension
 int launch_dense_scan_group(anrag_index *idx, hipStream_t stream, const float *const *d_queries, int32_t n_queries,
                             int32_t k, const uint32_t *d_allow_bits, float *d_scores_out, const int *sets,
-                            int64_t scores_stride = 0);
+                            int64_t scores_stride = 0, const PendingTail *pending = nullptr);
 int launch_bm25_lists(anrag_index *idx, hipStream_t st, const int32_t *d_terms, int32_t n_terms, int32_t k,
                       const uint32_t *d_allow_bits, double *d_scores_out, int set);
 int launch_bm25_lists_group(anrag_index *idx, hipStream_t st, const int32_t *const *d_terms, const int32_t *n_terms,

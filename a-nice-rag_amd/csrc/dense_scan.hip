@@ -78,12 +78,61 @@ struct ScanQueries {
     int32_t n;
 };
 
+// The list merge of the PREVIOUS single query of the same stream, done by one extra workgroup of this launch (the
+// lists are complete: the launch that wrote them has finished).  A query submitted alone used to cost a marker on the
+// scans' stream plus a merge kernel on another stream waiting for it: hipEventRecord alone is 4-5 us of stream time per
+// query on this stack (scripts/exp/launch_gap.hip), a tenth of a 100k-row pass.  out == nullptr: nothing to merge.
+struct DeferredTail {
+    const float *blk_s;
+    const uint32_t *blk_r;
+    int32_t n_lists, k;
+    const int64_t *doc;
+    int64_t base;
+    anrag_candidate *out;
+};
+
+// 4 waves: the dense half of query_tail_kernel (tail.hip) -- same merge network, same records
+__device__ __forceinline__ void dense_tail_block(const DeferredTail &dt) {
+    __shared__ float lf_s[4 * kListLen];
+    __shared__ uint32_t lf_r[4 * kListLen];
+    const int lane = lane_id(), wave = threadIdx.x / kWave;
+    WaveTopK<float> tf;
+    tf.init(dt.k);
+    merge_lists(tf, dt.blk_s, dt.blk_r, dt.n_lists, dt.k, wave, 4);
+    for (int half = 2; half >= 1; half >>= 1) {
+        if (wave >= half && wave < 2 * half) {
+            lf_s[wave * kListLen + lane] = tf.s;
+            lf_r[wave * kListLen + lane] = tf.r;
+        }
+        __syncthreads();
+        if (wave < half) tf.merge_sorted(lf_s + (wave + half) * kListLen, lf_r + (wave + half) * kListLen);
+        __syncthreads();
+    }
+    if (wave == 0 && lane < dt.k) {
+        const bool empty = tf.r == kNoRow;
+        anrag_candidate c;
+        c.doc = empty ? -1 : (dt.doc ? dt.doc[tf.r] : dt.base + (int64_t)tf.r);
+        c.score = empty ? -__builtin_huge_val() : (double)tf.s;
+        dt.out[lane] = c;
+    }
+}
+
 template <int G, int CH, int R, bool FILTER, bool SCORES, int THREADS = kScanThreads>
 __global__ __launch_bounds__(THREADS) void dense_scan_kernel(
     const float *__restrict__ emb, ScanQueries Q, int64_t n_rows, int32_t dim, int32_t k,
     const uint16_t *__restrict__ src, const uint32_t *__restrict__ allow_bits, float *__restrict__ scores_out,
-    int64_t scores_stride) {
+    int64_t scores_stride, DeferredTail dt) {
     constexpr int GROUPS = kWave / G;  // rows per wave-load
+    int scan_blocks = gridDim.x;
+    if constexpr (!SCORES && THREADS == 4 * kWave) {
+        if (dt.out != nullptr) {  // the last workgroup of the launch merges the previous query's lists
+            scan_blocks -= 1;
+            if ((int)blockIdx.x == scan_blocks) {
+                dense_tail_block(dt);
+                return;
+            }
+        }
+    }
     constexpr int RW = GROUPS * R;     // rows per wave iteration
     constexpr int WAVES = THREADS / kWave;
     __shared__ uint32_t lds_allow[FILTER ? 2048 : 1];  // 65536 source ids
@@ -201,7 +250,7 @@ __global__ __launch_bounds__(THREADS) void dense_scan_kernel(
             finish_row(base + r * GROUPS + grp, acc, part_sid[r]);
         }
     };
-    const int64_t step = (int64_t)gridDim.x * WAVES * RW;
+    const int64_t step = (int64_t)scan_blocks * WAVES * RW;
     const int64_t base0 = ((int64_t)blockIdx.x * WAVES + wave) * RW;
     if (base0 >= n_rows) {  // a wave without rows (tiny corpora): empty lists
         top.init(1);
@@ -442,9 +491,25 @@ int launch_dense_scan(anrag_index *idx, hipStream_t st, const float *d_query, in
 
 // n <= kScanGroupMax queries in ONE launch, query i into block-list set sets[i] -- or, with d_scores_out, every score
 // of query i to d_scores_out + i * scores_stride (the full-ranking tile, rank_batch.hip)
+bool dense_scan_has_shape(const anrag_index *idx) {
+    return scan_dispatch(idx->dim, [](auto) {});
+}
+
 int launch_dense_scan_group(anrag_index *idx, hipStream_t st, const float *const *d_queries, int32_t n_queries, int32_t k,
-                            const uint32_t *d_allow_bits, float *d_scores_out, const int *sets, int64_t scores_stride) {
+                            const uint32_t *d_allow_bits, float *d_scores_out, const int *sets, int64_t scores_stride,
+                            const PendingTail *pending) {
     ANRAG_REQUIRE(n_queries >= 1 && n_queries <= kScanGroupMax, "scan group of %d queries", n_queries);
+    ANRAG_REQUIRE(!pending || (!d_scores_out && dense_scan_has_shape(idx)), "deferred list merge: shaped scan kernels only");
+    DeferredTail dt{};
+    if (pending) {
+        dt.blk_s = idx->d_blk_score_f32 + (int64_t)pending->set * kMaxScanLists * kListLen;
+        dt.blk_r = idx->d_blk_row_a + (int64_t)pending->set * kMaxScanLists * kListLen;
+        dt.n_lists = dense_scan_lists(idx);
+        dt.k = pending->k;
+        dt.doc = idx->d_dense_doc;
+        dt.base = idx->dense_doc_base;
+        dt.out = pending->out;
+    }
     ANRAG_REQUIRE(!d_scores_out || n_queries == 1 || scores_stride >= idx->n_rows, "score tile rows overlap");
     const int64_t n = idx->n_rows;
     ScanQueries Q;
@@ -466,8 +531,8 @@ int launch_dense_scan_group(anrag_index *idx, hipStream_t st, const float *const
         const bool done = scan_dispatch(d, [&](auto shape) {
             using S = decltype(shape);
 #define ANRAG_SCAN(F, SC)                                                                                  \
-    dense_scan_kernel<S::kG, S::kCH, S::kR, F, SC><<<grid, kScanThreads, 0, st>>>(                            \
-        idx->d_emb, Q, idx->n_rows, idx->dim, k, idx->d_dense_src, allow, d_scores_out, scores_stride)
+    dense_scan_kernel<S::kG, S::kCH, S::kR, F, SC><<<grid + (pending ? 1 : 0), kScanThreads, 0, st>>>(        \
+        idx->d_emb, Q, idx->n_rows, idx->dim, k, idx->d_dense_src, allow, d_scores_out, scores_stride, dt)
             if (d_scores_out) {
                 if (allow) ANRAG_SCAN(true, true); else ANRAG_SCAN(false, true);
             } else {

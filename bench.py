@@ -674,7 +674,117 @@ def also_measurements(args, torch, nat, lib, idx, Index, synth, E, Q, T, n_terms
                           "what": "sum over query terms of df(t) x 12 B, one launch per query, idle GPU"}
         res["tail"] = {"kernel": "query_tail_kernel (list merge -> top-k records)", "bound": "latency",
                        "avg_launch_us": ms_t / max(n_t, 1) * 1e3, "launches": n_t}
+        # ---- K3 with 8 queries per launch (anrag_bm25_search_group_device): the launch and the tail are paid once per group
+        import ctypes as C
+
+        PT = (C.c_void_p * qn)(*[T[i].data_ptr() for i in range(qn)])
+        PO = (C.c_void_p * qn)(*[outk[i].data_ptr() for i in range(qn)])
+        PN = (C.c_int32 * qn)(*[int(x) for x in n_terms])
+        gq = qn // 8 * 8
+        def run_groups(n):
+            for i in range(0, n, 8):
+                o = i % gq
+                nat.check(lib.anrag_bm25_search_group_device(
+                    idx.handle, C.cast(C.byref(PT, o * 8), C.c_void_p), C.cast(C.byref(PN, o * 4), C.c_void_p), 8, K, None,
+                    C.cast(C.byref(PO, o * 8), C.c_void_p)))
+            idx.sync()
+        if gq >= 8:
+            run_groups(gq)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            run_groups(8 * gq)
+            wall8 = time.perf_counter() - t0
+            idx.profile(True, kernels=[nat.KERNEL_BM25], every=1)
+            idx.profile_reset()
+            run_groups(2 * gq)
+            ms8, n8 = idx.profile_read(nat.KERNEL_BM25)
+            u8 = idx.profile_units(nat.KERNEL_BM25)
+            idx.profile(False)
+            us_q = ms8 / max(u8, 1) * 1e3
+            res["k3_bm25_8_per_launch"] = {
+                "kernel": "bm25_kernel (K3), 8 queries per launch (a workgroup set per query)", "bound": "hbm (latency-dominated)",
+                "algorithmic_bytes_per_query": byts, "avg_launch_us": ms8 / max(n8, 1) * 1e3, "launches": n8,
+                "us_per_query_in_kernel": us_q, "achieved": byts / (us_q * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": byts / (us_q * 1e-6) / 1e9 / HBM_PEAK_GBS, "queries_per_s_bm25_only": 8 * gq / wall8}
+    # ---- full-ranking mode for query lists (retrieval_eval.py's similarity_k = common_sections_n = 12000)
+    try:
+        res.update(full_ranking_measurements(args, torch, idx, Index, synth, E, Q, T, n_terms, post, device, local_rank))
+    except Exception as e:  # a side measurement must not take the headline down
+        res["full_ranking_error"] = repr(e)
     return res
+
+
+def full_ranking_measurements(args, torch, idx, Index, synth, E, Q, T, n_terms, post, device, local_rank):
+    """`anrag_rank_batch` (rank_batch.hip) against the per-query entry points it replaces, wall-clock through the C ABI
+    from host operands: (1) the reference's own corpus shape, 9,609 x 384 + BM25, 2,048 hybrid queries, k = 12,000 >= N
+    (every list is a full ranking: sort, not select); (2) this run's corpus (k = 12,000 << N: radix select first)."""
+    from anrag.index import rank_batch
+
+    out = {}
+    KF = 12000
+
+    def measure(name, dense_idx, bm_idx, q_host, term_lists, n_dense, dim, n_docs, df, sample):
+        nq = len(term_lists)
+        legs = [dict(index=dense_idx, weight=W_DENSE, queries=q_host), dict(index=bm_idx, weight=W_BM25, term_lists=term_lists)]
+        space = max(n_dense, n_docs)
+        rank_batch(legs, nq, KF, WRRF_K, KF, id_space=space)  # warm-up: scratch pool, LDS attributes
+        t0 = time.perf_counter()
+        ids, _, cnt = rank_batch(legs, nq, KF, WRRF_K, KF, id_space=space)
+        t_ids = (time.perf_counter() - t0) / nq
+        expect = ids[:, 0].copy()
+        t0 = time.perf_counter()
+        _, _, _, ranks = rank_batch(legs, nq, KF, WRRF_K, KF, id_space=space, expect=expect, want_ids=False)
+        t_rank = (time.perf_counter() - t0) / nq
+        kd, kb = min(KF, n_dense), min(KF, n_docs)
+        t0 = time.perf_counter()
+        same = True
+        for i in range(sample):  # the per-query path: score dump + library sort of all N, three more sorts for the fusion
+            dd, _, dc = dense_idx.dense_search(q_host[i], kd)
+            bd, _, bc = bm_idx.bm25_search(term_lists[i], kb)
+            fid, _ = dense_idx.wrrf([dd[0, :int(dc[0])], bd[:bc]], [W_DENSE, W_BM25], WRRF_K, KF)
+            same = same and fid.tolist() == ids[i, :cnt[i]].tolist()
+        t_single = (time.perf_counter() - t0) / sample
+        touched = float(np.mean([sum(int(df[t]) for t in tl if t >= 0) for tl in term_lists]))
+        byts = (n_dense * dim * 4 + 2 * n_dense * 4) + (touched * 12 + 2 * n_docs * 8) + 2 * space * 12 + 2 * (kd + kb) * 4
+        out[name] = {
+            "what": "dense + BM25 full ranking and weighted RRF of %d queries in one anrag_rank_batch call, similarity_k = "
+                    "common_sections_n = %d (retrieval_eval.py:142-143); host operands in, host results out" % (nq, KF),
+            "rows": n_dense, "dim": dim, "bm25_docs": n_docs, "queries": nq,
+            "us_per_query_ids_out": t_ids * 1e6, "us_per_query_rank_of_expected_only": t_rank * 1e6,
+            "us_per_query_one_by_one": t_single * 1e6, "one_by_one_sample": sample,
+            "speedup_vs_one_by_one": t_single / t_ids, "speedup_rank_only": t_single / t_rank,
+            "ids_equal_one_by_one": bool(same), "rank_of_expected_ok": bool(np.all(ranks == 1)),
+            "algorithmic_bytes_per_query": byts, "bound": "hbm (score tiles) + lds (sorts)",
+            "achieved": byts / t_rank / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": byts / t_rank / 1e9 / HBM_PEAK_GBS,
+            "bytes_are": "corpus read + score tile written and read (dense N*D*4 + 2*N*4; BM25 sum df*12 + 2*N*8) + fusion "
+                         "arrays filled and read (2*U*12) + ranked lists written and read"}
+
+    # (1) the reference's corpus shape
+    n1, d1 = 9609, 384
+    E1 = synth.dense_corpus(n1, d1, CORPUS_SEED + 7, device)
+    Q1, _ = synth.dense_queries(E1, 2048, QUERY_SEED + 7)
+    post1 = synth.bm25_postings(n1, 50_000, BM25_SEED + 7, device)
+    df1 = post1["df"].cpu().numpy()
+    idf1 = synth.bm25_idf(df1, n1)
+    t1 = [np.asarray(t, np.int32) for t in synth.bm25_queries(post1, 128, QUERY_SEED + 8)]
+    t1 = [t1[i % len(t1)] for i in range(2048)]
+    torch.cuda.synchronize()
+    with Index(local_rank) as c1:
+        c1.dense_load((E1.data_ptr(), n1, d1))
+        c1.bm25_load(post1["indptr"], (post1["post_doc"].data_ptr(), post1["post_doc"].numel()),
+                     (post1["post_tf"].data_ptr(), post1["post_tf"].numel()), idf1, post1["doc_len"],
+                     float(post1["total_len"]) / n1, synth.BM25_K1, synth.BM25_B)
+        measure("full_ranking_9609x384_k12000", c1, c1, Q1.cpu().numpy(), t1, n1, d1, n1, df1, 16)
+    del E1, post1
+    # (2) this run's corpus
+    if post is not None and E.shape[0] >= 100_000:
+        nq = min(64, Q.shape[0])
+        qh = Q[:nq].cpu().numpy()
+        tl = [T[i, : n_terms[i]].cpu().numpy().astype(np.int32) for i in range(nq)]
+        df = np.diff(post["indptr"])
+        measure("full_ranking_%dx%d_k12000" % (E.shape[0], E.shape[1]), idx, idx, qh, tl, int(E.shape[0]), int(E.shape[1]),
+                int(len(post["doc_len"])), df, 4)
+    return out
 
 
 # ====================================================================== CPU port beside it

@@ -161,12 +161,14 @@ int anrag_dense_search_f64(anrag_index *idx, const double *query, int32_t k,
                            const uint8_t *allow_source, int32_t n_sources, int64_t *out_doc,
                            double *out_score, int32_t *out_count);
 
-/* Same, all operands in HBM, no host sync: d_out is n_queries x k
- * anrag_candidate.  The scans run back to back on the primary stream, each
- * query's list merge on the fusion stream under the next scan: results are
- * complete in fusion-stream order (anrag_index_sync waits for everything).
- * n_queries > 1: up to 8 queries share a scan launch (each is still its own pass
- * over the matrix; a workgroup starts the next query when it has finished this one).
+/* Same, all operands in HBM, no host sync: d_out is n_queries x k anrag_candidate.
+ * n_queries > 1: up to 8 queries share a scan launch (each is still its own pass over the matrix; a workgroup starts
+ * the next query when it has finished this one); every query's list merge runs on the fusion stream under the following
+ * scans: results are complete in fusion-stream order.
+ * n_queries == 1 on the index's own streams (no anrag_index_set_streams): consecutive calls rotate over up to 4 scan
+ * streams whose kernels overlap, and a query's list merge rides in the NEXT scan launch of its stream -- no marker, no
+ * merge launch per query (a launch boundary, ramp and drain are a fifth of a 100k-row pass).  Results are complete
+ * after anrag_index_sync or behind anrag_index_signal_stream (which launch the merges still pending).
  * d_allow_bits: nullable device bitmap, bit s of word s/32 = source s allowed. */
 int anrag_dense_search_device(anrag_index *idx, const float *d_queries, int32_t n_queries,
                               int32_t k, const uint32_t *d_allow_bits, anrag_candidate *d_out);
