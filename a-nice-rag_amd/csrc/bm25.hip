@@ -40,6 +40,7 @@ constexpr int kBm25Threads = 1024;
 constexpr int kBm25ThreadsSmall = 256;
 constexpr int kPostPerThread = 4;  // documents per thread in the selection
 constexpr int kMaxPartDocs = kPostPerThread * kBm25Threads;
+constexpr int kDocsPerThreadTall = kMaxPartDocs / kBm25ThreadsSmall;  // 16: the 256-thread form over 4,096 documents
 constexpr int kFrequentDf = 1024;  // rarer terms carry no partition table: the whole list is gathered, range-checked
 constexpr int kTermBatch = 128;
 
@@ -99,8 +100,8 @@ __device__ unsigned long long g_k3_stamps[4096 * 12];
 constexpr int kWorkDoubles = 2048;                 // work area, 16 KB
 constexpr int kRoundTerms = 16;                    // query terms gathered per round at most
 constexpr int kRoundSlots = 16;                    // (term, 1024-posting chunk) pairs per round = loads per thread
-constexpr int bm25_lds_bytes(int threads) {
-    return kPostPerThread * threads * 8 + kWorkDoubles * 8 + kTermBatch * (8 + 8 + 4 + 4) + 2048 * 4 +
+constexpr int bm25_lds_bytes(int threads, int dpt = kPostPerThread) {
+    return dpt * threads * 8 + kWorkDoubles * 8 + kTermBatch * (8 + 8 + 4 + 4) + 2048 * 4 +
            kRoundSlots * (8 + 8 + 4) + 16 + 12 * 8;
 }
 constexpr int kSurvCap = 1024;                     // survivors of the selection bound kept in LDS (12 KB)
@@ -126,7 +127,14 @@ struct Bm25Queries {
     double *scores[kScanGroupMax];      // n_docs scores (SCORES form)
 };
 
-template <bool FILTER, bool SCORES, int THREADS>
+// DPT: documents per thread (THREADS * DPT = the largest partition the form takes).  Three forms:
+//   <1024, 4>  4,096-document partitions, 16 waves: round 2's kernel.  VALU-issue bound: ~1,500 instructions per wave
+//              whatever the query touches, 16 waves on one CU's four SIMDs = 9-10 us
+//   < 256, 4>  partitions of <= 1,024 documents (the shards of a multi-GPU run, small corpora)
+//   < 256,16>  4,096-document partitions with a QUARTER of the waves: the per-wave overhead (term table, slot rounds,
+//              barriers) is paid by 4 waves instead of 16, the document-proportional part of the selection grows 4x
+//              per thread; two workgroups share a CU (LDS), so in query groups one's latency hides under the other
+template <bool FILTER, bool SCORES, int THREADS, int DPT = kPostPerThread>
 __global__ __launch_bounds__(THREADS, THREADS == kBm25Threads ? 5 : 1) void bm25_kernel(
     const int64_t *__restrict__ indptr, const int32_t *__restrict__ post_doc, const double *__restrict__ impact,
     const double *__restrict__ idf, const int32_t *__restrict__ part_slot, const int32_t *__restrict__ part_ptr,
@@ -140,7 +148,7 @@ __global__ __launch_bounds__(THREADS, THREADS == kBm25Threads ? 5 : 1) void bm25
     extern __shared__ __attribute__((aligned(16))) unsigned char bm25_lds[];
     double *slice = reinterpret_cast<double *>(bm25_lds);
     constexpr int WAVES = THREADS / kWave;
-    double *st_val = slice + kPostPerThread * THREADS;  // work area
+    double *st_val = slice + DPT * THREADS;  // work area
     double *t_w = st_val + kWorkDoubles;
     int64_t *t_base = reinterpret_cast<int64_t *>(t_w + kTermBatch);
     int32_t *t_begin = reinterpret_cast<int32_t *>(t_base + kTermBatch);
@@ -335,13 +343,13 @@ __global__ __launch_bounds__(THREADS, THREADS == kBm25Threads ? 5 : 1) void bm25
         constexpr int ROT = LPG == 16 ? 4 : 16;
         const int g = tid / LPG, gl = tid % LPG;
         constexpr int kCmp = kWave / WAVES;  // comparisons per wave and ranked entry
-        double sc[kPostPerThread];
-        uint32_t rw[kPostPerThread];
-        bool okk[kPostPerThread];
+        double sc[DPT];
+        uint32_t rw[DPT];
+        bool okk[DPT];
         double bs = neg_inf<double>();
         uint32_t br = kNoRow;
 #pragma unroll
-        for (int u = 0; u < kPostPerThread; ++u) {
+        for (int u = 0; u < DPT; ++u) {
             const int j = gl + LPG * u;
             const int i = 64 * j + ((g + ROT * j) & 63);
             okk[u] = i < len;
@@ -396,10 +404,10 @@ __global__ __launch_bounds__(THREADS, THREADS == kBm25Threads ? 5 : 1) void bm25
         {
             const double ts = *tau_s;
             const uint32_t tr = *tau_r;
-            unsigned long long m[kPostPerThread];
+            unsigned long long m[DPT];
             int total = 0;
 #pragma unroll
-            for (int u = 0; u < kPostPerThread; ++u) {
+            for (int u = 0; u < DPT; ++u) {
                 m[u] = __ballot(okk[u] && !beats(ts, tr, sc[u], rw[u]));
                 total += __builtin_popcountll(m[u]);
             }
@@ -409,7 +417,7 @@ __global__ __launch_bounds__(THREADS, THREADS == kBm25Threads ? 5 : 1) void bm25
                 base = __builtin_amdgcn_readfirstlane(base);
             }
 #pragma unroll
-            for (int u = 0; u < kPostPerThread; ++u) {
+            for (int u = 0; u < DPT; ++u) {
                 if ((m[u] >> lane) & 1ull) {
                     const int pos = base + __builtin_popcountll(m[u] & ((1ull << lane) - 1ull));
                     if (pos < kSurvCap) {
@@ -462,14 +470,14 @@ __global__ __launch_bounds__(THREADS, THREADS == kBm25Threads ? 5 : 1) void bm25
                 double fs = neg_inf<double>();  // the thread's best document (rows ascend with u)
                 uint32_t fr = kNoRow;
 #pragma unroll
-                for (int u = 0; u < kPostPerThread; ++u)
+                for (int u = 0; u < DPT; ++u)
                     if (okk[u] && (fr == kNoRow || sc[u] > fs)) {
                         fs = sc[u];
                         fr = rw[u];
                     }
                 top.offer_lanes(fr != kNoRow && top.admits(fs, fr), fs, fr);
 #pragma unroll
-                for (int u = 0; u < kPostPerThread; ++u)
+                for (int u = 0; u < DPT; ++u)
                     top.offer_lanes(okk[u] && rw[u] != fr && top.admits(sc[u], rw[u]), sc[u], rw[u]);
                 block_merge(top, lds_s, lds_r, WAVES);
             }
@@ -551,8 +559,10 @@ int bm25_load(anrag_index *idx, const int64_t *indptr, int64_t n_terms, const in
     idx->bm25_b = b;
     idx->bm25_avgdl = avgdl;
     idx->bm25_doc_base = doc_id_base;
-    // partitioning: about one workgroup per CU, slices of at most 32 KB
-    int64_t pd = (n_docs + idx->n_cus - 1) / idx->n_cus;
+    // partitioning: about `per_cu` workgroups per CU, slices of at most 32 KB
+    int per_cu = 1;
+    if (const char *env = getenv("ANRAG_BM25_PARTS_PER_CU")) per_cu = std::max(1, std::min(16, atoi(env)));
+    int64_t pd = (n_docs + (int64_t)idx->n_cus * per_cu - 1) / ((int64_t)idx->n_cus * per_cu);
     pd = ((pd + 255) / 256) * 256;
     pd = std::max<int64_t>(256, std::min<int64_t>(kMaxPartDocs, pd));
     idx->part_docs = (int32_t)pd;
@@ -659,8 +669,9 @@ int launch_bm25_lists_group(anrag_index *idx, hipStream_t st, const int32_t *con
     const uint32_t *allow = idx->d_bm25_src ? d_allow_bits : nullptr;
     int rc;
     // dynamic LDS is asked for explicitly (up to 60 KB per workgroup), per device
-#define ANRAG_BM25_ATTR(F, S, T)                                                                                     \
-    if ((rc = ensure_dynamic_lds(idx->device, reinterpret_cast<const void *>(&bm25_kernel<F, S, T>), bm25_lds_bytes(T)))) \
+#define ANRAG_BM25_ATTR(F, S, T, D)                                                                                  \
+    if ((rc = ensure_dynamic_lds(idx->device, reinterpret_cast<const void *>(&bm25_kernel<F, S, T, D>),             \
+                                 bm25_lds_bytes(T, D))))                                                            \
         return rc
     Bm25Queries Q;
     for (int i = 0; i < kScanGroupMax; ++i) {
@@ -673,21 +684,28 @@ int launch_bm25_lists_group(anrag_index *idx, hipStream_t st, const int32_t *con
     }
     {
         LaunchTimer t(idx, ANRAG_KERNEL_BM25, st, n_queries);
-        // partitions of <= 1,024 documents: the 256-thread form (one wave per SIMD, cheaper barriers)
+        // partitions of <= 1,024 documents: the 256-thread form (one wave per SIMD, cheaper barriers).  Larger ones: a
+        // query alone takes the 1,024-thread form (its 16 waves finish a partition soonest: 17.6 against 23.8 us per
+        // launch at 1M documents), a GROUP the 256-thread x 16-document form (two workgroups share a CU and a quarter
+        // of the waves pay the per-wave overhead: 10.6 against 11.2 us per query at 8 queries per launch, 6.4 against
+        // 8.6 for 2-term queries).  ANRAG_BM25_FORM=wide / tall forces one of them (measurements).
         const bool small = idx->part_docs <= kPostPerThread * kBm25ThreadsSmall;
+        static const int forced = [] { const char *e = getenv("ANRAG_BM25_FORM"); return !e ? 0 : (e[0] == 'w' ? 1 : (e[0] == 't' ? 2 : 0)); }();
+        const bool wide = forced == 1 || (forced == 0 && n_queries == 1);
         const dim3 grid((unsigned)idx->n_parts, (unsigned)n_queries);
-#define ANRAG_BM25_T(F, S, T)                                                                                     \
+#define ANRAG_BM25_T(F, S, T, D)                                                                                  \
     do {                                                                                                          \
-        ANRAG_BM25_ATTR(F, S, T);                                                                                 \
-        bm25_kernel<F, S, T><<<grid, T, bm25_lds_bytes(T), st>>>(                                                  \
+        ANRAG_BM25_ATTR(F, S, T, D);                                                                              \
+        bm25_kernel<F, S, T, D><<<grid, T, bm25_lds_bytes(T, D), st>>>(                                            \
             idx->d_indptr, idx->d_post_doc, idx->d_post_impact, idx->d_idf, idx->d_part_slot, idx->d_part_ptr,    \
             idx->n_parts, idx->part_docs, idx->n_docs, idx->n_terms, Q, k, idx->d_bm25_src, allow,                \
             idx->n_postings);                                                                                     \
     } while (0)
-#define ANRAG_BM25(F, S)                                                   \
-    do {                                                                   \
-        if (small) ANRAG_BM25_T(F, S, kBm25ThreadsSmall);                  \
-        else ANRAG_BM25_T(F, S, kBm25Threads);                             \
+#define ANRAG_BM25(F, S)                                                                      \
+    do {                                                                                      \
+        if (small) ANRAG_BM25_T(F, S, kBm25ThreadsSmall, kPostPerThread);                     \
+        else if (wide) ANRAG_BM25_T(F, S, kBm25Threads, kPostPerThread);                      \
+        else ANRAG_BM25_T(F, S, kBm25ThreadsSmall, kDocsPerThreadTall);                       \
     } while (0)
         if (d_scores_out) {
             if (allow) ANRAG_BM25(true, true); else ANRAG_BM25(false, true);

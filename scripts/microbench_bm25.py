@@ -18,7 +18,7 @@ dev = torch.device("cuda:0")
 post = synth.bm25_postings(n, 200_000, 777, dev)
 df = post["df"].cpu().numpy()
 idf = synth.bm25_idf(df, n)
-terms = synth.bm25_queries(post, 64, 99)
+terms = synth.bm25_queries(post, 64, 99, n_terms=int(os.environ.get("N_TERMS", "9")))
 torch.cuda.synchronize()
 idx = Index(0)
 idx.bm25_load(post["indptr"], (post["post_doc"].data_ptr(), post["post_doc"].numel()),
