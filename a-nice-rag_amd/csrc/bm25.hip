@@ -345,21 +345,22 @@ __global__ __launch_bounds__(THREADS, THREADS == kBm25Threads ? 5 : 1) void bm25
         constexpr int kCmp = kWave / WAVES;  // comparisons per wave and ranked entry
         double sc[DPT];
         uint32_t rw[DPT];
-        bool okk[DPT];
+        uint32_t okbits = 0;  // bit u: the lane's u-th document counts (inside the partition, allowed source)
         double bs = neg_inf<double>();
         uint32_t br = kNoRow;
 #pragma unroll
         for (int u = 0; u < DPT; ++u) {
             const int j = gl + LPG * u;
             const int i = 64 * j + ((g + ROT * j) & 63);
-            okk[u] = i < len;
+            bool ok_u = i < len;
             sc[u] = neg_inf<double>();
             rw[u] = kNoRow;
-            if (okk[u]) {
+            if (ok_u) {
                 sc[u] = slice[i];
-                if constexpr (FILTER) okk[u] = source_ok(lds_allow, src[lo + i]);
+                if constexpr (FILTER) ok_u = source_ok(lds_allow, src[lo + i]);
             }
-            if (okk[u]) {
+            okbits |= (ok_u ? 1u : 0u) << u;
+            if (ok_u) {
                 rw[u] = (uint32_t)(lo + i);
                 if (br == kNoRow || sc[u] > bs) {  // rows ascend with u: a strict > keeps the lower row among equals
                     bs = sc[u];
@@ -404,12 +405,15 @@ __global__ __launch_bounds__(THREADS, THREADS == kBm25Threads ? 5 : 1) void bm25
         {
             const double ts = *tau_s;
             const uint32_t tr = *tau_r;
-            unsigned long long m[DPT];
+            // the lane's survivors as bits of one register; the wave-wide masks are formed again where they are needed
+            // (DPT of them held at once were 32 SGPRs: the 16-document form spilled 27)
+            uint32_t keep = 0;
             int total = 0;
 #pragma unroll
             for (int u = 0; u < DPT; ++u) {
-                m[u] = __ballot(okk[u] && !beats(ts, tr, sc[u], rw[u]));
-                total += __builtin_popcountll(m[u]);
+                const bool kp = ((okbits >> u) & 1u) && !beats(ts, tr, sc[u], rw[u]);
+                keep |= (kp ? 1u : 0u) << u;
+                total += __builtin_popcountll(__ballot(kp));
             }
             int base = 0;
             if (total > 0) {
@@ -418,14 +422,15 @@ __global__ __launch_bounds__(THREADS, THREADS == kBm25Threads ? 5 : 1) void bm25
             }
 #pragma unroll
             for (int u = 0; u < DPT; ++u) {
-                if ((m[u] >> lane) & 1ull) {
-                    const int pos = base + __builtin_popcountll(m[u] & ((1ull << lane) - 1ull));
+                const unsigned long long mu = __ballot((keep >> u) & 1u);
+                if ((mu >> lane) & 1ull) {
+                    const int pos = base + __builtin_popcountll(mu & ((1ull << lane) - 1ull));
                     if (pos < kSurvCap) {
                         surv_s[pos] = sc[u];
                         surv_r[pos] = rw[u];
                     }
                 }
-                base += __builtin_popcountll(m[u]);
+                base += __builtin_popcountll(mu);
             }
         }
         __syncthreads();
@@ -471,14 +476,14 @@ __global__ __launch_bounds__(THREADS, THREADS == kBm25Threads ? 5 : 1) void bm25
                 uint32_t fr = kNoRow;
 #pragma unroll
                 for (int u = 0; u < DPT; ++u)
-                    if (okk[u] && (fr == kNoRow || sc[u] > fs)) {
+                    if (((okbits >> u) & 1u) && (fr == kNoRow || sc[u] > fs)) {
                         fs = sc[u];
                         fr = rw[u];
                     }
                 top.offer_lanes(fr != kNoRow && top.admits(fs, fr), fs, fr);
 #pragma unroll
                 for (int u = 0; u < DPT; ++u)
-                    top.offer_lanes(okk[u] && rw[u] != fr && top.admits(sc[u], rw[u]), sc[u], rw[u]);
+                    top.offer_lanes(((okbits >> u) & 1u) && rw[u] != fr && top.admits(sc[u], rw[u]), sc[u], rw[u]);
                 block_merge(top, lds_s, lds_r, WAVES);
             }
             if (threadIdx.x < kWave) {

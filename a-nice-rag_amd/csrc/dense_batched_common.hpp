@@ -36,8 +36,11 @@ __device__ __forceinline__ SurvBuf surv_buf(unsigned char *slice, int entries) {
 
 // (Few, narrow arguments on purpose, here and below: one argument more than fit the argument registers went through
 // the stack, which turns on scratch memory for the whole kernel -- the f32 full pass ran 20 % slower for it.)
-static __device__ __noinline__ void flush_survivors(unsigned char *slice, int entries, int n, int32_t *__restrict__ cnt,
-                                                    Cand32 *__restrict__ cand) {
+// flush_survivors_body is inlined into tile_survivors, so that function stays a LEAF: a non-inlined function that
+// calls another one has to save its return address on the stack, and that alone gave every full-pass kernel a 16-byte
+// private segment (scratch set up for the whole launch).  tests/test_build_resources.py holds all K2 kernels to 0.
+static __device__ __forceinline__ void flush_survivors_body(unsigned char *slice, int entries, int n,
+                                                            int32_t *__restrict__ cnt, Cand32 *__restrict__ cand) {
     constexpr int32_t cap = kCandCap;
     const SurvBuf b = surv_buf(slice, entries);
     for (int i = lane_id(); i < n; i += kWave) {
@@ -53,6 +56,10 @@ static __device__ __noinline__ void flush_survivors(unsigned char *slice, int en
     // atomics and stores count in vmcnt like the LDS-DMA copies of the split-precision kernel: drain them, so that its
     // counted waits keep meaning "my copies of the stage two back have landed"
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+}
+static __device__ __noinline__ void flush_survivors(unsigned char *slice, int entries, int n, int32_t *__restrict__ cnt,
+                                                    Cand32 *__restrict__ cand) {
+    flush_survivors_body(slice, entries, n, cnt, cand);
 }
 
 // The per-score path for one 32 x 32 accumulator tile that holds at least one survivor (lane = query column q -- -1
@@ -83,7 +90,7 @@ __device__ __noinline__ int tile_survivors(f32x16 v, uint32_t row0, int q, float
         }
         fill += __builtin_popcountll(m);
         if (fill > ENTRIES - kWave) {
-            flush_survivors(slice, ENTRIES, fill, cnt, cand);
+            flush_survivors_body(slice, ENTRIES, fill, cnt, cand);
             fill = 0;
         }
     }
@@ -111,6 +118,26 @@ __device__ __forceinline__ void batched_tile_epilogue(f32x16 (&acc)[TI][TJ], int
         // of the k best sampled rows share one lane's 16 TI rows).  Writing every score (16.7M four-byte stores scattered
         // over 256 query rows, then read back by the threshold kernel) was the larger part of the pre-pass.
         const int64_t n_tiles = (n_work + 2 * TI * 32 - 1) / (2 * TI * 32);
+        // which of the lane's TI x 16 rows count (inside the sample, allowed source): ONE bit per row, worked out before
+        // the query columns are walked -- a row's source does not depend on the column.  (Asking per column doubled the
+        // source loads, and the filtered sampled pass of the split kernel spilled 118 registers over them; ti is NOT
+        // unrolled here so that at most 16 source loads are in flight -- acc is not touched in this loop.)
+        static_assert(TI * 16 <= 64, "one bit per row of the lane");
+        unsigned long long okbits = 0;
+#pragma unroll 1
+        for (int ti = 0; ti < TI; ++ti) {
+            uint32_t bits = 0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t wr = tile * (2 * TI * 32) + rw * (TI * 32) + ti * 32 + 4 * lh + (r & 3) + 8 * (r >> 2);
+                bool ok = wr < n_work;
+                if constexpr (FILTER) {
+                    if (ok) ok = source_ok(allow_bits, src[wr * stride]);
+                }
+                bits |= (ok ? 1u : 0u) << r;
+            }
+            okbits |= (unsigned long long)bits << (ti * 16);
+        }
 #pragma unroll
         for (int tj = 0; tj < TJ; ++tj) {
             float b1 = neg_inf<float>(), b2 = neg_inf<float>();
@@ -118,13 +145,9 @@ __device__ __forceinline__ void batched_tile_epilogue(f32x16 (&acc)[TI][TJ], int
             for (int ti = 0; ti < TI; ++ti)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int64_t wr = tile * (2 * TI * 32) + rw * (TI * 32) + ti * 32 + 4 * lh + (r & 3) + 8 * (r >> 2);
                     float s = acc[ti][tj][r];
                     if (s != s) s = __builtin_huge_valf();  // NaN ranks first, as in K1 (and in numpy)
-                    bool ok = wr < n_work;
-                    if constexpr (FILTER) {
-                        if (ok) ok = source_ok(allow_bits, src[wr * stride]);
-                    }
+                    const bool ok = (okbits >> (ti * 16 + r)) & 1ull;
                     if (!ok) s = neg_inf<float>();
                     const float lo = s < b1 ? s : b1;  // the smaller of (s, b1) competes for second place
                     b1 = s < b1 ? b1 : s;

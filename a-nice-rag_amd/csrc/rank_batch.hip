@@ -33,10 +33,19 @@ constexpr int kRankCtrlWords = 64;
 constexpr int kRankLoads = 8;  // independent loads per thread and step of a pass over a segment
 constexpr uint32_t kTiePosBits = 26;  // fusion insertion key = leg << 26 | position in the leg's list
 
-// W 32-bit words per composite: [W-1] most significant.  fp32 key: {~tie, key bits}; fp64: {~tie, key lo, key hi}.
+// W 32-bit words per composite, w0 least significant.  fp32 key: {~tie, key bits}; fp64: {~tie, key lo, key hi}.
+// (Named members, not an array: an array that any path indexes with a variable lives in scratch memory.)
 template <int W>
-struct Comp {
-    uint32_t w[W];
+struct Comp;
+template <>
+struct Comp<2> {
+    uint32_t w0, w1;
+};
+template <>
+struct Comp<3> {
+    uint32_t w0;  // ~tie
+    uint64_t k;   // key bits (words 1 and 2) -- kept as ONE 64-bit value: as three words the compiler assembled the
+                  // 64-bit views it needs through a stack slot (store w0, store {w1,w2}, load {w0,w1}: 16 B of scratch)
 };
 template <int W>
 constexpr int rank_cap() { return W == 2 ? 16384 : 13312; }
@@ -62,27 +71,20 @@ __device__ __forceinline__ double unorder_bits(uint64_t u) {
     return __longlong_as_double((long long)((u >> 63) ? (u ^ 0x8000000000000000ull) : ~u));
 }
 
-__device__ __forceinline__ Comp<2> make_comp(float key, uint32_t tie) {
-    Comp<2> c;
-    c.w[0] = ~tie;
-    c.w[1] = order_bits(key);
-    return c;
-}
+__device__ __forceinline__ Comp<2> make_comp(float key, uint32_t tie) { return Comp<2>{~tie, order_bits(key)}; }
 __device__ __forceinline__ Comp<3> make_comp(double key, uint32_t tie) {
-    const uint64_t u = order_bits(key);
-    Comp<3> c;
-    c.w[0] = ~tie;
-    c.w[1] = (uint32_t)u;
-    c.w[2] = (uint32_t)(u >> 32);
-    return c;
+    return Comp<3>{~tie, order_bits(key)};
 }
-__device__ __forceinline__ uint64_t hi64(const Comp<2> &c) { return ((uint64_t)c.w[1] << 32) | c.w[0]; }
-__device__ __forceinline__ uint64_t hi64(const Comp<3> &c) { return ((uint64_t)c.w[2] << 32) | c.w[1]; }
+__device__ __forceinline__ Comp<2> comp_zero(Comp<2> *) { return Comp<2>{0, 0}; }
+__device__ __forceinline__ Comp<3> comp_zero(Comp<3> *) { return Comp<3>{0, 0}; }
+__device__ __forceinline__ uint64_t hi64(const Comp<2> &c) { return ((uint64_t)c.w1 << 32) | c.w0; }
+__device__ __forceinline__ uint64_t hi64(const Comp<3> &c) { return c.k; }
+__device__ __forceinline__ uint64_t lo64(const Comp<3> &c) { return (c.k << 32) | c.w0; }
 
 __device__ __forceinline__ bool comp_gt(const Comp<2> &a, const Comp<2> &b) { return hi64(a) > hi64(b); }
 __device__ __forceinline__ bool comp_gt(const Comp<3> &a, const Comp<3> &b) {
     const uint64_t x = hi64(a), y = hi64(b);
-    return x > y || (x == y && a.w[0] > b.w[0]);
+    return x > y || (x == y && a.w0 > b.w0);
 }
 
 // bits [lo, lo + len) of the composite, counted from its least significant bit; len <= 11, lo wave-uniform
@@ -90,7 +92,7 @@ __device__ __forceinline__ uint32_t comp_bits(const Comp<2> &c, int lo, int len)
     return (uint32_t)(hi64(c) >> lo) & ((1u << len) - 1u);
 }
 __device__ __forceinline__ uint32_t comp_bits(const Comp<3> &c, int lo, int len) {
-    const uint64_t v = lo >= 32 ? hi64(c) >> (lo - 32) : (((uint64_t)c.w[1] << 32) | c.w[0]) >> lo;
+    const uint64_t v = lo >= 32 ? hi64(c) >> (lo - 32) : lo64(c) >> lo;
     return (uint32_t)v & ((1u << len) - 1u);
 }
 // do the top `pbits` bits of c equal those of pre?
@@ -101,23 +103,40 @@ __device__ __forceinline__ bool comp_match(const Comp<3> &c, const Comp<3> &pre,
     if (pbits == 0) return true;
     const uint64_t d = hi64(c) ^ hi64(pre);
     if (pbits <= 64) return (d >> (64 - pbits)) == 0;
-    return d == 0 && ((c.w[0] ^ pre.w[0]) >> (96 - pbits)) == 0;
+    return d == 0 && ((c.w0 ^ pre.w0) >> (96 - pbits)) == 0;
 }
-__device__ __forceinline__ void comp_or_bits(Comp<2> &c, uint32_t v, int lo) {
+__device__ __forceinline__ Comp<2> comp_or_bits(Comp<2> c, uint32_t v, int lo) {
     const uint64_t x = hi64(c) | ((uint64_t)v << lo);
-    c.w[0] = (uint32_t)x;
-    c.w[1] = (uint32_t)(x >> 32);
+    return Comp<2>{(uint32_t)x, (uint32_t)(x >> 32)};
 }
-__device__ __forceinline__ void comp_or_bits(Comp<3> &c, uint32_t v, int lo) {
+__device__ __forceinline__ Comp<3> comp_or_bits(Comp<3> c, uint32_t v, int lo) {
     if (lo >= 32) {
-        const uint64_t x = hi64(c) | ((uint64_t)v << (lo - 32));
-        c.w[1] = (uint32_t)x;
-        c.w[2] = (uint32_t)(x >> 32);
-    } else {
-        const uint64_t x = (((uint64_t)c.w[1] << 32) | c.w[0]) | ((uint64_t)v << lo);
-        c.w[0] = (uint32_t)x;
-        c.w[1] = (uint32_t)(x >> 32);
+        return Comp<3>{c.w0, c.k | ((uint64_t)v << (lo - 32))};
     }
+    const uint64_t x = lo64(c) | ((uint64_t)v << lo);  // bits 0..63 of the composite: w0 and the low key word
+    return Comp<3>{(uint32_t)x, (c.k & 0xFFFFFFFF00000000ull) | (x >> 32)};
+}
+// survivor i of the LDS arrays (word w of survivor i at arr[w * CAP + i])
+template <int CAP>
+__device__ __forceinline__ void comp_store(uint32_t *arr, int i, const Comp<2> &c) {
+    arr[i] = c.w0;
+    arr[CAP + i] = c.w1;
+}
+template <int CAP>
+__device__ __forceinline__ void comp_store(uint32_t *arr, int i, const Comp<3> &c) {
+    arr[i] = c.w0;
+    arr[CAP + i] = (uint32_t)c.k;
+    arr[2 * CAP + i] = (uint32_t)(c.k >> 32);
+}
+template <int CAP>
+__device__ __forceinline__ void comp_load(const uint32_t *arr, int i, Comp<2> &c) {
+    c.w0 = arr[i];
+    c.w1 = arr[CAP + i];
+}
+template <int CAP>
+__device__ __forceinline__ void comp_load(const uint32_t *arr, int i, Comp<3> &c) {
+    c.w0 = arr[i];
+    c.k = ((uint64_t)arr[2 * CAP + i] << 32) | arr[CAP + i];
 }
 
 // ------------------------------------------------------------------ select + sort, one workgroup per segment
@@ -152,13 +171,11 @@ __global__ __launch_bounds__(kRankThreads) void seg_topk_sort_kernel(
     const KEY *__restrict__ kp = keys + seg * key_stride;
     const uint32_t *__restrict__ tp = TIE ? ties + seg * tie_stride : nullptr;
 
-    Comp<W> thr;  // survivors = candidates whose composite is not below thr
-#pragma unroll
-    for (int w = 0; w < W; ++w) thr.w[w] = 0;
+    Comp<W> thr = comp_zero((Comp<W> *)nullptr);  // survivors = candidates whose composite is not below thr
     int32_t k_eff = kq;  // min(kq, candidates), known after the first pass (n > CAP) or after the compaction
 
     // one pass over the segment: f(key, tie word) for every element, kRankLoads independent loads per thread in flight
-    auto for_each = [&](auto &&f) {
+    auto for_each = [&](auto &&f) __attribute__((always_inline)) {
         for (int32_t base = 0; base < n; base += T * kRankLoads) {
             KEY kv[kRankLoads];
             uint32_t tv[kRankLoads];
@@ -186,7 +203,7 @@ __global__ __launch_bounds__(kRankThreads) void seg_topk_sort_kernel(
             const int nb = 1 << len;
             for (int i = tid; i < nb; i += T) hist[i] = 0;
             __syncthreads();
-            for_each([&](KEY key, uint32_t tie) {
+            for_each([&](KEY key, uint32_t tie) __attribute__((always_inline)) {
                 const Comp<W> c = make_comp(key, tie);
                 const bool cand = key != neg_inf<KEY>() && comp_match(c, thr, pbits);
                 const uint32_t bin = comp_bits(c, lo, len);
@@ -246,7 +263,7 @@ __global__ __launch_bounds__(kRankThreads) void seg_topk_sort_kernel(
             const uint32_t bin = ctrl[2], acc = ctrl[3], inbin = ctrl[4];
             above += acc;
             k_rem -= (int32_t)acc;
-            comp_or_bits(thr, bin, lo);
+            thr = comp_or_bits(thr, bin, lo);
             pbits += len;
             if (above + inbin <= (uint32_t)CAP || pbits == B) break;
             __syncthreads();  // ctrl / hist are rewritten by the next pass
@@ -257,7 +274,7 @@ __global__ __launch_bounds__(kRankThreads) void seg_topk_sort_kernel(
     // compaction: candidates not below thr -> LDS (any order: they are sorted next)
     if (tid == 0) ctrl[0] = 0;
     __syncthreads();
-    for_each([&](KEY key, uint32_t tie) {
+    for_each([&](KEY key, uint32_t tie) __attribute__((always_inline)) {
         const Comp<W> c = make_comp(key, tie);
         const bool keep = key != neg_inf<KEY>() && !comp_gt(thr, c);
         const unsigned long long m = __ballot(keep);
@@ -267,10 +284,7 @@ __global__ __launch_bounds__(kRankThreads) void seg_topk_sort_kernel(
             base = read_lane(base, 0);
             if (keep) {
                 const uint32_t pos = base + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull));
-                if (pos < (uint32_t)CAP) {
-#pragma unroll
-                    for (int w = 0; w < W; ++w) arr[w * CAP + pos] = c.w[w];
-                }
+                if (pos < (uint32_t)CAP) comp_store<CAP>(arr, (int)pos, c);
             }
         }
     });
@@ -283,19 +297,13 @@ __global__ __launch_bounds__(kRankThreads) void seg_topk_sort_kernel(
     // entry DOWN in index they never move -- comparators that touch them are skipped, no padding is stored.
     int32_t v2 = 2;
     while (v2 < m) v2 <<= 1;
-    auto cmp_swap = [&](int32_t a, int32_t b) {
+    auto cmp_swap = [&](int32_t a, int32_t b) __attribute__((always_inline)) {
         Comp<W> x, y;
-#pragma unroll
-        for (int w = 0; w < W; ++w) {
-            x.w[w] = arr[w * CAP + a];
-            y.w[w] = arr[w * CAP + b];
-        }
+        comp_load<CAP>(arr, a, x);
+        comp_load<CAP>(arr, b, y);
         if (comp_gt(y, x)) {
-#pragma unroll
-            for (int w = 0; w < W; ++w) {
-                arr[w * CAP + a] = y.w[w];
-                arr[w * CAP + b] = x.w[w];
-            }
+            comp_store<CAP>(arr, a, y);
+            comp_store<CAP>(arr, b, x);
         }
     };
     const int32_t half_all = v2 >> 1;
