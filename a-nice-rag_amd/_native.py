@@ -110,7 +110,12 @@ def load_library() -> C.CDLL:
 
     lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
     for name, args in _SIGNATURES.items():
-        fn = getattr(lib, name)
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:
+            if os.environ.get("ANRAG_LIB"):  # another build of the library (an older one, for A/B measurements)
+                continue
+            raise
         fn.argtypes = args
         fn.restype = C.c_int
     lib.anrag_last_error.argtypes = []

@@ -134,17 +134,20 @@ struct Bm25Queries {
 //   < 256,16>  4,096-document partitions with a QUARTER of the waves: the per-wave overhead (term table, slot rounds,
 //              barriers) is paid by 4 waves instead of 16, the document-proportional part of the selection grows 4x
 //              per thread; two workgroups share a CU (LDS), so in query groups one's latency hides under the other
-template <bool FILTER, bool SCORES, int THREADS, int DPT = kPostPerThread>
+// GROUPED: the launch carries several queries (blockIdx.y picks one: a scalar load at a computed offset in front of
+// everything else); a launch of ONE query reads its operands at fixed kernarg offsets with the rest of the arguments.
+template <bool FILTER, bool SCORES, int THREADS, int DPT = kPostPerThread, bool GROUPED = true>
 __global__ __launch_bounds__(THREADS, THREADS == kBm25Threads ? 5 : 1) void bm25_kernel(
     const int64_t *__restrict__ indptr, const int32_t *__restrict__ post_doc, const double *__restrict__ impact,
     const double *__restrict__ idf, const int32_t *__restrict__ part_slot, const int32_t *__restrict__ part_ptr,
     int32_t n_parts, int32_t part_docs, int64_t n_docs, int64_t n_vocab, Bm25Queries Q, int32_t k,
     const uint16_t *__restrict__ src, const uint32_t *__restrict__ allow_bits, int64_t sentinel) {
-    const int32_t *__restrict__ terms = Q.terms[blockIdx.y];
-    const int32_t n_terms = Q.n_terms[blockIdx.y];
-    double *__restrict__ blk_score = Q.blk_score[blockIdx.y];
-    uint32_t *__restrict__ blk_row = Q.blk_row[blockIdx.y];
-    double *__restrict__ scores_out = Q.scores[blockIdx.y];
+    const int qy = GROUPED ? (int)blockIdx.y : 0;
+    const int32_t *__restrict__ terms = Q.terms[qy];
+    const int32_t n_terms = Q.n_terms[qy];
+    double *__restrict__ blk_score = Q.blk_score[qy];
+    uint32_t *__restrict__ blk_row = Q.blk_row[qy];
+    double *__restrict__ scores_out = Q.scores[qy];
     extern __shared__ __attribute__((aligned(16))) unsigned char bm25_lds[];
     double *slice = reinterpret_cast<double *>(bm25_lds);
     constexpr int WAVES = THREADS / kWave;
@@ -674,8 +677,8 @@ int launch_bm25_lists_group(anrag_index *idx, hipStream_t st, const int32_t *con
     const uint32_t *allow = idx->d_bm25_src ? d_allow_bits : nullptr;
     int rc;
     // dynamic LDS is asked for explicitly (up to 60 KB per workgroup), per device
-#define ANRAG_BM25_ATTR(F, S, T, D)                                                                                  \
-    if ((rc = ensure_dynamic_lds(idx->device, reinterpret_cast<const void *>(&bm25_kernel<F, S, T, D>),             \
+#define ANRAG_BM25_ATTR(F, S, T, D, G)                                                                               \
+    if ((rc = ensure_dynamic_lds(idx->device, reinterpret_cast<const void *>(&bm25_kernel<F, S, T, D, G>),          \
                                  bm25_lds_bytes(T, D))))                                                            \
         return rc
     Bm25Queries Q;
@@ -698,13 +701,18 @@ int launch_bm25_lists_group(anrag_index *idx, hipStream_t st, const int32_t *con
         static const int forced = [] { const char *e = getenv("ANRAG_BM25_FORM"); return !e ? 0 : (e[0] == 'w' ? 1 : (e[0] == 't' ? 2 : 0)); }();
         const bool wide = forced == 1 || (forced == 0 && n_queries == 1);
         const dim3 grid((unsigned)idx->n_parts, (unsigned)n_queries);
-#define ANRAG_BM25_T(F, S, T, D)                                                                                  \
+#define ANRAG_BM25_TG(F, S, T, D, G)                                                                              \
     do {                                                                                                          \
-        ANRAG_BM25_ATTR(F, S, T, D);                                                                              \
-        bm25_kernel<F, S, T, D><<<grid, T, bm25_lds_bytes(T, D), st>>>(                                            \
+        ANRAG_BM25_ATTR(F, S, T, D, G);                                                                           \
+        bm25_kernel<F, S, T, D, G><<<grid, T, bm25_lds_bytes(T, D), st>>>(                                         \
             idx->d_indptr, idx->d_post_doc, idx->d_post_impact, idx->d_idf, idx->d_part_slot, idx->d_part_ptr,    \
             idx->n_parts, idx->part_docs, idx->n_docs, idx->n_terms, Q, k, idx->d_bm25_src, allow,                \
             idx->n_postings);                                                                                     \
+    } while (0)
+#define ANRAG_BM25_T(F, S, T, D)                                           \
+    do {                                                                   \
+        if (n_queries == 1) ANRAG_BM25_TG(F, S, T, D, false);              \
+        else ANRAG_BM25_TG(F, S, T, D, true);                              \
     } while (0)
 #define ANRAG_BM25(F, S)                                                                      \
     do {                                                                                      \
@@ -719,6 +727,7 @@ int launch_bm25_lists_group(anrag_index *idx, hipStream_t st, const int32_t *con
         }
 #undef ANRAG_BM25
 #undef ANRAG_BM25_T
+#undef ANRAG_BM25_TG
 #undef ANRAG_BM25_ATTR
         ANRAG_HIP(hipGetLastError());
     }

@@ -47,9 +47,10 @@ struct TailArgs : TailQuery {
     double w_dense, w_bm25, wrrf_k;
 };
 
+template <bool GROUPED>
 __global__ __launch_bounds__(kTailThreads) void query_tail_kernel(TailGroup grp) {
     TailArgs a;
-    static_cast<TailQuery &>(a) = grp.q[blockIdx.x];
+    static_cast<TailQuery &>(a) = grp.q[GROUPED ? (int)blockIdx.x : 0];  // one query: fixed kernarg offsets
     a.dense_doc = grp.dense_doc;
     a.dense_base = grp.dense_base;
     a.bm25_doc = grp.bm25_doc;
@@ -167,7 +168,8 @@ int launch_tail_group(anrag_index *idx, hipStream_t st, const int *sets, bool us
     a.w_bm25 = w_bm25;
     a.wrrf_k = wrrf_k;
     LaunchTimer t(idx, mode == kTailFuse ? ANRAG_KERNEL_WRRF : ANRAG_KERNEL_SELECT, st, n);
-    query_tail_kernel<<<n, kTailThreads, 0, st>>>(a);
+    if (n == 1) query_tail_kernel<false><<<1, kTailThreads, 0, st>>>(a);
+    else query_tail_kernel<true><<<n, kTailThreads, 0, st>>>(a);
     ANRAG_HIP(hipGetLastError());
     return ANRAG_OK;
 }

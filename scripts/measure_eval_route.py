@@ -42,6 +42,10 @@ def ask(i, cfg):
                                      wrrf_k=40, use_reranker=False, **cfg)
 
 
+from anrag.retrieval_eval import RetrievalEvaluator
+
+ev = RetrievalEvaluator(retrieval_system=system)
+big = max(nq, 2048)
 for name, cfg in configs.items():
     for i in range(3):
         r = ask(i, cfg)
@@ -49,7 +53,28 @@ for name, cfg in configs.items():
     for i in range(nq):
         r = ask(i, cfg)
     dt = (time.perf_counter() - t0) / nq
-    print(f"{name}: {dt*1e3:.2f} ms/query ({1/dt:.0f} q/s), {len(r)} ids returned", flush=True)
+    # the same questions as LISTS: retrieve_documents_batch (id strings out) and evaluate_queries (rank of the expected
+    # id only) -- one anrag_rank_batch per list (rank_batch.hip)
+    asks = [{"query_embeddings": {LOCAL_ENCODER_KEY: qv[i % len(qv)]}, "query_tokens": qt[i % len(qv)] or ["asthma"]}
+            for i in range(big)]
+    shared = dict(similarity_k=12000, common_sections_n=12000, filename_type_filter="CG,NG", wrrf_k=40, use_reranker=False,
+                  **cfg)
+    system.retrieve_documents_batch(asks, **shared)  # warm-up at full size: the scratch pool grows once
+    t0 = time.perf_counter()
+    lists = system.retrieve_documents_batch(asks, **shared)
+    dl = (time.perf_counter() - t0) / big
+    same = all(lists[i] == ask(i, cfg) for i in range(4))
+    items = [{"query": "", "expected_id": lists[i][min(7, len(lists[i]) - 1)], "query_embeddings": a["query_embeddings"],
+              "query_tokens": a["query_tokens"]} for i, a in enumerate(asks)]
+    params = dict(shared)
+    ev.evaluate_queries(items, params)
+    t0 = time.perf_counter()
+    res = ev.evaluate_queries(items, params)
+    de = (time.perf_counter() - t0) / big
+    ok = all(r_["rank"] == min(7, len(lists[i]) - 1) + 1 for i, r_ in enumerate(res))
+    print(f"{name}: one by one {dt*1e3:.2f} ms/query ({1/dt:.0f} q/s), {len(r)} ids returned; as a list of {big}: "
+          f"{dl*1e6:.0f} us/query with the id strings ({1/dl:.0f} q/s; equal to one-by-one: {same}), "
+          f"{de*1e6:.1f} us/query for the evaluation harness's rank-of-expected ({1/de:.0f} q/s; ranks right: {ok})", flush=True)
 pr = cProfile.Profile(); pr.enable()
 for i in range(20):
     ask(i, configs["hybrid full ranking"])
