@@ -476,7 +476,7 @@ def run_rank(args) -> int:
 def carried_traffic(n_rows, dim, queries_per_launch):
     """HBM bytes per K1 launch from the PMC counters.  NOT measured in this run (rocprofv3 --pmc needs its own
     passes): carried over from the committed collection for this shape, and labelled as such."""
-    for name in ("r02_pmc_dense_scan.json",):
+    for name in ("r03_pmc_dense_scan.json", "r02_pmc_dense_scan.json"):
         path = os.path.join(REPO, "profiles", name)
         try:
             with open(path) as f:
