@@ -756,13 +756,14 @@ def full_ranking_measurements(args, torch, idx, Index, synth, E, Q, T, n_terms, 
         t_rank = (time.perf_counter() - t0) / nq
         kd, kb = min(KF, n_dense), min(KF, n_docs)
         t0 = time.perf_counter()
-        same = True
+        singles = []
         for i in range(sample):  # the per-query path: score dump + library sort of all N, three more sorts for the fusion
             dd, _, dc = dense_idx.dense_search(q_host[i], kd)
             bd, _, bc = bm_idx.bm25_search(term_lists[i], kb)
             fid, _ = dense_idx.wrrf([dd[0, :int(dc[0])], bd[:bc]], [W_DENSE, W_BM25], WRRF_K, KF)
-            same = same and fid.tolist() == ids[i, :cnt[i]].tolist()
+            singles.append(fid)
         t_single = (time.perf_counter() - t0) / sample
+        same = all(np.array_equal(f, ids[i, :cnt[i]]) for i, f in enumerate(singles))
         touched = float(np.mean([sum(int(df[t]) for t in tl if t >= 0) for tl in term_lists]))
         byts = (n_dense * dim * 4 + 2 * n_dense * 4) + (touched * 12 + 2 * n_docs * 8) + 2 * space * 12 + 2 * (kd + kb) * 4
         out[name] = {
