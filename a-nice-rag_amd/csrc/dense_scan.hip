@@ -187,10 +187,23 @@ __global__ __launch_bounds__(THREADS) void dense_scan_kernel(
         }
         top.init(SCORES ? 1 : k);
     };
-    auto flush = [&](int32_t qi) {  // the wave's sorted list of query qi
+    // row range of this wave.  List-keeping form: rows interleaved over all waves of the grid, `step` apart.  SCORES: a
+    // contiguous block per wave (see finish_row).
+    constexpr int RW_ = (kWave / G) * R;
+    const int64_t total_waves = (int64_t)scan_blocks * (THREADS / kWave);
+    const int64_t wave_global = (int64_t)blockIdx.x * (THREADS / kWave) + threadIdx.x / kWave;
+    const int64_t rows_per_wave = ((n_rows + total_waves - 1) / total_waves + RW_ - 1) / RW_ * RW_;
+    const int64_t scan_base0 = SCORES ? wave_global * rows_per_wave : wave_global * RW_;
+    const int64_t scan_lim = SCORES ? (scan_base0 + rows_per_wave < n_rows ? scan_base0 + rows_per_wave : n_rows) : n_rows;
+    float sc_buf = 0.f;
+    int64_t sc_base = scan_base0;
+    auto flush = [&](int32_t qi) {  // the wave's sorted list of query qi (SCORES: the scores still parked)
         if constexpr (!SCORES) {
             Q.blk_s[qi][(blockIdx.x * WAVES + wave) * kListLen + lane] = top.s;
             Q.blk_r[qi][(blockIdx.x * WAVES + wave) * kListLen + lane] = top.r;
+        } else {
+            if (sc_base + lane < scan_lim) scores_out[(int64_t)qi * scores_stride + sc_base + lane] = sc_buf;
+            sc_base = scan_base0;
         }
     };
     // One batch = R row-groups of this wave: R*CH dwordx4 loads per lane.  The loop is software-pipelined over
@@ -211,12 +224,30 @@ __global__ __launch_bounds__(THREADS) void dense_scan_kernel(
     float part[R];        // SPLIT == 2: the first half's partial dot products
     uint32_t part_sid[R];
     int32_t qi = 0;  // the query whose batch is being reduced (SCORES: query qi's scores start at qi * scores_stride)
+    // SCORES: a wave owns a CONTIGUOUS block of rows [base0, lim) (the list-keeping form interleaves the waves' rows) and
+    // parks its scores in one register, lane j <- row sc_base + j, stored 64 at a time as one 256-byte piece.  One 4- or
+    // 8-byte store per wave and step (the interleaved form's) put a store between every two batches of loads -- stores
+    // count in vmcnt like loads, so the counted waits waited for them too: 479 us against 430 us per 1M-row pass.
     auto finish_row = [&](int64_t row, float acc, uint32_t sid) {
         acc = nan_first(group_sum<G>(acc));
         bool ok = row < n_rows;
         if constexpr (FILTER) ok = ok && source_ok(lds_allow, sid);
         if constexpr (SCORES) {
-            if (leader && row < n_rows) scores_out[(int64_t)qi * scores_stride + row] = ok ? acc : neg_inf<float>();
+            const float val = ok ? acc : neg_inf<float>();
+            const int64_t row0 = row - grp;  // the row of lane group 0: wave-uniform
+#pragma unroll
+            for (int g = 0; g < GROUPS; ++g) {
+                const float sg = read_lane(val, g * G + G - 1);
+                const int64_t rg = row0 + g;
+                if (rg < scan_lim) {
+                    const int slot = (int)(rg - sc_base);
+                    sc_buf = lane == slot ? sg : sc_buf;
+                    if (slot == kWave - 1) {
+                        scores_out[(int64_t)qi * scores_stride + sc_base + lane] = sc_buf;
+                        sc_base += kWave;
+                    }
+                }
+            }
         } else {
             const uint32_t r32 = (uint32_t)row;
             top.offer_lanes(leader && ok && top.admits(acc, r32), acc, r32);
@@ -250,8 +281,8 @@ __global__ __launch_bounds__(THREADS) void dense_scan_kernel(
             finish_row(base + r * GROUPS + grp, acc, part_sid[r]);
         }
     };
-    const int64_t step = (int64_t)scan_blocks * WAVES * RW;
-    const int64_t base0 = ((int64_t)blockIdx.x * WAVES + wave) * RW;
+    const int64_t step = SCORES ? RW : (int64_t)scan_blocks * WAVES * RW;
+    const int64_t base0 = scan_base0;
     if (base0 >= n_rows) {  // a wave without rows (tiny corpora): empty lists
         top.init(1);
         for (int32_t qe = 0; qe < Q.n; ++qe) flush(qe);
@@ -274,7 +305,7 @@ __global__ __launch_bounds__(THREADS) void dense_scan_kernel(
             reduce_first_half(b0);
             int32_t nq = qi;
             int64_t next = base + step;
-            if (next >= n_rows) {
+            if (next >= scan_lim) {
                 next = base0;
                 ++nq;
             }
@@ -293,7 +324,7 @@ __global__ __launch_bounds__(THREADS) void dense_scan_kernel(
     for (;;) {
         int32_t nq = qi;
         int64_t next = base + step;
-        if (next >= n_rows) {
+        if (next >= scan_lim) {
             next = base0;
             ++nq;
         }
@@ -307,7 +338,7 @@ __global__ __launch_bounds__(THREADS) void dense_scan_kernel(
         }
         base = next;
         next = base + step;
-        if (next >= n_rows) {
+        if (next >= scan_lim) {
             next = base0;
             ++nq;
         }
