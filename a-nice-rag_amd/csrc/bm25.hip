@@ -97,20 +97,31 @@ __device__ unsigned long long g_k3_stamps[4096 * 12];
 //   slice[4096] fp64 scores | work area (the selection's survivor / merge lists) | term table | allow bitmap |
 //   the gather round's slot table.  Postings are NOT staged in LDS: they go from HBM to registers and from there
 //   into the slice.
-constexpr int kWorkDoubles = 2048;                 // work area, 16 KB
 constexpr int kRoundTerms = 16;                    // query terms gathered per round at most
-constexpr int kRoundSlots = 16;                    // (term, 1024-posting chunk) pairs per round = loads per thread
-constexpr int bm25_lds_bytes(int threads, int dpt = kPostPerThread) {
-    return dpt * threads * 8 + kWorkDoubles * 8 + kTermBatch * (8 + 8 + 4 + 4) + 2048 * 4 +
-           kRoundSlots * (8 + 8 + 4) + 16 + 12 * 8;
+// per form: work area (the selection's survivor / merge lists), survivors kept in LDS, slots of a gather round
+constexpr int work_doubles(int threads) { return threads == kBm25Threads ? 2048 : 1024; }   // 16 KB / 8 KB
+constexpr int surv_cap(int threads) { return threads == kBm25Threads ? 1024 : 512; }
+// (term, THREADS-posting chunk) pairs per round = loads per thread.  The 256-thread x 16-document form takes 32: its
+// 4,096-document partitions hold ~27 chunks of 256 postings for a 9-term query, and every extra round is a slot table, a
+// barrier and a memory round trip (7-8 us of its 17 us were two to three rounds); at one wave per SIMD and three
+// workgroups per CU it can afford the registers (<= 168).
+constexpr int round_slots(int threads, int dpt) { return threads == kBm25ThreadsSmall && dpt == kDocsPerThreadTall ? 24 : 16; }
+constexpr int bm25_lds_bytes(int threads, int dpt, bool filter) {
+    return dpt * threads * 8 + work_doubles(threads) * 8 + kTermBatch * (8 + 8 + 4 + 4) + (filter ? 2048 * 4 : 0) +
+           round_slots(threads, dpt) * (8 + 8 + 4) + 16 + 12 * 8;
 }
-constexpr int kSurvCap = 1024;                     // survivors of the selection bound kept in LDS (12 KB)
-static_assert(kBm25Threads / kWave * kListLen * (8 + 4) <= kWorkDoubles * 8, "merge lists must fit in the work area");
-static_assert((kSurvCap + kSurvCap / 2 + kWave + kWave / 2 + 4 + kWave / 2) * 8 <= kWorkDoubles * 8,
+static_assert(kBm25Threads / kWave * kListLen * (8 + 4) <= work_doubles(kBm25Threads) * 8 &&
+                  kBm25ThreadsSmall / kWave * kListLen * (8 + 4) <= work_doubles(kBm25ThreadsSmall) * 8,
+              "merge lists must fit in the work area");
+static_assert((surv_cap(kBm25Threads) + surv_cap(kBm25Threads) / 2 + kWave + kWave / 2 + 4 + kWave / 2) * 8 <=
+                      work_doubles(kBm25Threads) * 8 &&
+                  (surv_cap(kBm25ThreadsSmall) + surv_cap(kBm25ThreadsSmall) / 2 + kWave + kWave / 2 + 4 + kWave / 2) * 8 <=
+                      work_doubles(kBm25ThreadsSmall) * 8,
               "survivor lists must fit too");
 static_assert(kMaxPartDocs == 64 * 64 && kBm25Threads % (64 * 4) == 0 && kBm25ThreadsSmall % (64 * 4) == 0,
               "the selection deals the documents to 64 groups of THREADS / 64 lanes");
-static_assert((kFrequentDf + kBm25ThreadsSmall - 1) / kBm25ThreadsSmall <= kRoundSlots && kRoundTerms <= kWave,
+static_assert((kFrequentDf + kBm25ThreadsSmall - 1) / kBm25ThreadsSmall <= 16 && kRoundTerms <= kWave &&
+                  kMaxPartDocs / kBm25ThreadsSmall <= round_slots(kBm25ThreadsSmall, kDocsPerThreadTall),
               "a term alone must fit a round");
 
 // Register budget of the 1,024-thread form: its 16 waves (4 per SIMD) must fit NEXT TO a scan workgroup (one wave of up
@@ -137,7 +148,7 @@ struct Bm25Queries {
 // GROUPED: the launch carries several queries (blockIdx.y picks one: a scalar load at a computed offset in front of
 // everything else); a launch of ONE query reads its operands at fixed kernarg offsets with the rest of the arguments.
 template <bool FILTER, bool SCORES, int THREADS, int DPT = kPostPerThread, bool GROUPED = true>
-__global__ __launch_bounds__(THREADS, THREADS == kBm25Threads ? 5 : 1) void bm25_kernel(
+__global__ __launch_bounds__(THREADS, THREADS == kBm25Threads ? 5 : (DPT == kDocsPerThreadTall ? 3 : 1)) void bm25_kernel(
     const int64_t *__restrict__ indptr, const int32_t *__restrict__ post_doc, const double *__restrict__ impact,
     const double *__restrict__ idf, const int32_t *__restrict__ part_slot, const int32_t *__restrict__ part_ptr,
     int32_t n_parts, int32_t part_docs, int64_t n_docs, int64_t n_vocab, Bm25Queries Q, int32_t k,
@@ -151,13 +162,14 @@ __global__ __launch_bounds__(THREADS, THREADS == kBm25Threads ? 5 : 1) void bm25
     extern __shared__ __attribute__((aligned(16))) unsigned char bm25_lds[];
     double *slice = reinterpret_cast<double *>(bm25_lds);
     constexpr int WAVES = THREADS / kWave;
+    constexpr int kWorkDoubles = work_doubles(THREADS), kSurvCap = surv_cap(THREADS), kRoundSlots = round_slots(THREADS, DPT);
     double *st_val = slice + DPT * THREADS;  // work area
     double *t_w = st_val + kWorkDoubles;
     int64_t *t_base = reinterpret_cast<int64_t *>(t_w + kTermBatch);
     int32_t *t_begin = reinterpret_cast<int32_t *>(t_base + kTermBatch);
     int32_t *t_cnt = t_begin + kTermBatch;
     uint32_t *lds_allow = reinterpret_cast<uint32_t *>(t_cnt + kTermBatch);
-    int64_t *s_at = reinterpret_cast<int64_t *>(lds_allow + 2048);  // the gather round's slots (see there)
+    int64_t *s_at = reinterpret_cast<int64_t *>(lds_allow + (FILTER ? 2048 : 0));  // the gather round's slots (see there)
     double *s_w = reinterpret_cast<double *>(s_at + kRoundSlots);
     int32_t *s_cnt = reinterpret_cast<int32_t *>(s_w + kRoundSlots);
     int32_t *r_info = s_cnt + kRoundSlots;
@@ -223,6 +235,11 @@ __global__ __launch_bounds__(THREADS, THREADS == kBm25Threads ? 5 : 1) void bm25
         while (j0 < nb) {
             // the round's terms [j0, j1): greedy, at least one (a term alone always fits), at most kRoundTerms.
             // Lane t < kRoundTerms prices term j0 + t and writes its slots.
+            if (tid < kRoundSlots) {  // (wave 0; the term lanes' writes below follow in program order)
+                s_at[tid] = sentinel;  // every slot starts idle
+                s_w[tid] = 0.0;
+                s_cnt[tid] = 0;
+            }
             if (tid < kRoundTerms) {
                 // lane t's own count; the slots ahead of it by a scan over the 16 lanes (DPP row shifts, no LDS)
                 const int32_t mine = j0 + tid < nb ? t_cnt[j0 + tid] : 0;
@@ -234,9 +251,6 @@ __global__ __launch_bounds__(THREADS, THREADS == kBm25Threads ? 5 : 1) void bm25
                 incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xF, 0xF, true);  // row_shr:8
                 const int32_t before = incl - ns;
                 const bool in = j0 + tid < nb && incl <= kRoundSlots;
-                s_at[tid] = sentinel;  // kRoundTerms == kRoundSlots lanes: every slot starts idle
-                s_w[tid] = 0.0;
-                s_cnt[tid] = 0;
                 if (tid == 0) r_info[1] = 0;
                 if (in && ns > 0) {  // same wave: these LDS writes follow the initialisation above in program order
                     const int64_t at = t_base[j0 + tid] + t_begin[j0 + tid];
@@ -263,16 +277,16 @@ __global__ __launch_bounds__(THREADS, THREADS == kBm25Threads ? 5 : 1) void bm25
             int32_t g_doc[kRoundSlots];
             double g_val[kRoundSlots];
 #pragma unroll
-            for (int h = 0; h < kRoundSlots; h += kRoundSlots / 2) {  // table entries half a round at a time: registers
-                int32_t c[kRoundSlots / 2];
-                int64_t a[kRoundSlots / 2];
+            for (int h = 0; h < kRoundSlots; h += 8) {  // table entries eight at a time: registers
+                int32_t c[8];
+                int64_t a[8];
 #pragma unroll
-                for (int u = 0; u < kRoundSlots / 2; ++u) {
+                for (int u = 0; u < 8; ++u) {
                     c[u] = s_cnt[h + u + lane_zero];
                     a[u] = s_at[h + u + lane_zero];
                 }
 #pragma unroll
-                for (int u = 0; u < kRoundSlots / 2; ++u) {
+                for (int u = 0; u < 8; ++u) {
                     const int64_t at = tid < c[u] ? a[u] + tid : sentinel;
                     g_doc[h + u] = post_doc[at];
                     g_val[h + u] = impact[at];
@@ -290,12 +304,12 @@ __global__ __launch_bounds__(THREADS, THREADS == kBm25Threads ? 5 : 1) void bm25
             // VGPRs on every SIMD) -- K3 then ran BETWEEN the scans instead of under them (125k-row shard: 61 -> 104
             // us per query).
 #pragma unroll
-            for (int h = 0; h < kRoundSlots; h += kRoundSlots / 2) {
-                double g_w[kRoundSlots / 2];
+            for (int h = 0; h < kRoundSlots; h += 8) {
+                double g_w[8];
 #pragma unroll
-                for (int u = 0; u < kRoundSlots / 2; ++u) g_w[u] = s_w[h + u + lane_zero];
+                for (int u = 0; u < 8; ++u) g_w[u] = s_w[h + u + lane_zero];
 #pragma unroll
-                for (int u = 0; u < kRoundSlots / 2; ++u) {
+                for (int u = 0; u < 8; ++u) {
                     const int64_t d = g_doc[h + u];
                     // ds_add_f64: one LDS instruction instead of read -> wait -> add -> write (the slice is touched
                     // once per document and term, so this is the same IEEE addition, without the read's latency in
@@ -496,9 +510,10 @@ __global__ __launch_bounds__(THREADS, THREADS == kBm25Threads ? 5 : 1) void bm25
         }
         K3_STAMP(6);
 #ifdef ANRAG_K3_STAMPS
-        if (threadIdx.x == 0 && blockIdx.x < 4096) {
+        const unsigned k3_wg = blockIdx.y * gridDim.x + blockIdx.x;  // (query of the group, partition)
+        if (threadIdx.x == 0 && k3_wg < 4096) {
             k3_lds_stamps[7] = __builtin_amdgcn_s_memtime() - k3_cycles0;
-            for (int i = 0; i < 12; ++i) g_k3_stamps[blockIdx.x * 12 + i] = k3_lds_stamps[i];
+            for (int i = 0; i < 12; ++i) g_k3_stamps[k3_wg * 12 + i] = k3_lds_stamps[i];
         }
 #endif
     }
@@ -679,7 +694,7 @@ int launch_bm25_lists_group(anrag_index *idx, hipStream_t st, const int32_t *con
     // dynamic LDS is asked for explicitly (up to 60 KB per workgroup), per device
 #define ANRAG_BM25_ATTR(F, S, T, D, G)                                                                               \
     if ((rc = ensure_dynamic_lds(idx->device, reinterpret_cast<const void *>(&bm25_kernel<F, S, T, D, G>),          \
-                                 bm25_lds_bytes(T, D))))                                                            \
+                                 bm25_lds_bytes(T, D, F))))                                                         \
         return rc
     Bm25Queries Q;
     for (int i = 0; i < kScanGroupMax; ++i) {
@@ -704,7 +719,7 @@ int launch_bm25_lists_group(anrag_index *idx, hipStream_t st, const int32_t *con
 #define ANRAG_BM25_TG(F, S, T, D, G)                                                                              \
     do {                                                                                                          \
         ANRAG_BM25_ATTR(F, S, T, D, G);                                                                           \
-        bm25_kernel<F, S, T, D, G><<<grid, T, bm25_lds_bytes(T, D), st>>>(                                         \
+        bm25_kernel<F, S, T, D, G><<<grid, T, bm25_lds_bytes(T, D, F), st>>>(                                         \
             idx->d_indptr, idx->d_post_doc, idx->d_post_impact, idx->d_idf, idx->d_part_slot, idx->d_part_ptr,    \
             idx->n_parts, idx->part_docs, idx->n_docs, idx->n_terms, Q, k, idx->d_bm25_src, allow,                \
             idx->n_postings);                                                                                     \

@@ -69,4 +69,7 @@ def test_no_kernel_spills_or_uses_scratch(tmp_path):
         if m and int(m.group(1)) * int(m.group(2)) * 4 <= 3072 and not (int(m.group(1)) in (16, 32) and int(m.group(2)) == 5):
             assert int(k["vgpr_count"]) <= 128, f"{name}: {k['vgpr_count']} VGPRs (K3 must fit next to a scan wave)"
         if "bm25_kernel<" in name:
-            assert int(k["vgpr_count"]) <= 96, f"{name}: {k['vgpr_count']} VGPRs (5 waves per SIMD asked for)"
+            # the forms that run under a scan (one query: <1024, 4>; the shards' <256, 4>): 5 waves per SIMD; the
+            # 256 x 16 form of query groups runs three workgroups per CU at one wave per SIMD each
+            limit = 128 if ", 256, 16," in name else 96
+            assert int(k["vgpr_count"]) <= limit, f"{name}: {k['vgpr_count']} VGPRs (limit {limit})"
