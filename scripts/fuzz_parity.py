@@ -215,11 +215,154 @@ def run_big(budget: float = 60.0, seed: int = 0) -> int:
     return checks
 
 
+def run_rank(budget: float = 60.0, seed: int = 0) -> int:
+    """Full-ranking lists (`anrag_rank_batch`, rank_batch.hip) against the per-query entry points and the oracle: random
+    corpora below / around / above the sort kernel's LDS capacity (13,312 / 16,384 composites), shaped and odd dimensions,
+    duplicated rows and constant vectors (heavy ties at every cut), filters incl. one that keeps almost nothing, k from 1
+    to past the capacity of the smaller leg, 1 - 3 legs with permuted row -> document maps, queries without BM25 terms,
+    top_n below / above the fused length.  Single legs: ids and scores equal the per-query calls'; BM25 against the oracle
+    bit for bit; fusions bit for bit against the reference's dict + stable sort over the per-query lists.  Interleaved
+    with single dense queries on the scan lanes (their answers against `dense_search`)."""
+    from anrag.index import rank_batch, rank_caps
+    from anrag import _native as nat
+    import ctypes as C
+
+    cap32, cap64 = rank_caps()
+    rng = np.random.default_rng(seed)
+    t_end = time.time() + budget
+    rounds = checks = 0
+    while time.time() < t_end:
+        rounds += 1
+        n = int(rng.choice([3, 65, 1000, 4097, 9609, cap64 - 1, cap64, cap64 + 1, cap32, cap32 + 1, 20000, 40000]))
+        d = int(rng.choice([8, 64, 128, 384, 768]))
+        nb = int(rng.choice([max(2, n // 2), n, n + 50]))
+        n_src = int(rng.integers(1, 9))
+        e = rng.standard_normal((n, d), dtype=np.float32)
+        kind = rng.choice(["normal", "dups", "constant"])
+        if kind == "dups":
+            e[rng.integers(0, n, size=max(1, n // 3))] = e[0]
+        elif kind == "constant":
+            e[:] = e[0]  # every score equal: the order is the row order, every cut is inside a tie
+        sid = rng.integers(0, n_src, size=n).astype(np.uint16)
+        sidb = rng.integers(0, n_src, size=nb).astype(np.uint16)
+        vocab = int(rng.choice([4, 60, 3000]))
+        lens = rng.integers(0, 12, size=nb)
+        zipf = rng.zipf(1.3, size=int(lens.sum())) % vocab
+        corpus, at = [], 0
+        for L in lens:
+            corpus.append([str(t) for t in zipf[at: at + L]])
+            at += L
+        if not any(corpus):
+            corpus[0] = ["0"]
+        ref = BM25Okapi(corpus, k1=1.7, b=0.83, epsilon=0.05)
+        bi = Bm25Index(corpus, k1=1.7, b=0.83, epsilon=0.05)
+        space = max(n, nb) + 7
+        map_d = rng.permutation(space)[:n].astype(np.int64)
+        map_b = rng.permutation(space)[:nb].astype(np.int64)
+        log("rank corpus", rounds, "n", n, "d", d, "nb", nb, kind, "vocab", vocab)
+        with Index(0) as di, Index(0) as bx:
+            di.dense_load(e, source_id=sid)
+            bx.bm25_load(bi.indptr, bi.post_doc, bi.post_tf, bi.idf, bi.doc_len, bi.avgdl, bi.k1, bi.b, source_id=sidb)
+            lib = nat.load_library()
+            for trial in range(3):
+                nq = int(rng.choice([1, 3, 8, 9, 21]))
+                k = int(rng.choice([1, 7, 64, 65, 300, 12000, min(cap64, nb), min(cap32, n)]))
+                if min(k, nb) > cap64 or min(k, n) > cap32:
+                    continue
+                top_n = int(rng.choice([1, 15, k, 2 * k + 5]))
+                allow_d = None if rng.random() < 0.5 else (rng.random(n_src) < rng.choice([0.1, 0.6])).astype(np.uint8)
+                allow_b = None if allow_d is None else allow_d
+                q = e[rng.integers(0, n, size=nq)] + 0.1 * rng.standard_normal((nq, d)).astype(np.float32)
+                q = np.ascontiguousarray(q, dtype=np.float32)
+                tls = [bi.term_ids([str(t) for t in rng.integers(0, vocab + 2, size=int(rng.integers(0, 7)))]) for _ in range(nq)]
+                log("  trial", trial, "nq", nq, "k", k, "top_n", top_n, "filter", allow_d is not None)
+                # per-query lists (the library-sort path for k > 64, the register top-k below)
+                dl, bl = [], []
+                for i in range(nq):
+                    doc, sc_, cnt = di.dense_search(q[i], k, allow_d)
+                    dl.append((doc[0, :int(cnt[0])], sc_[0, :int(cnt[0])]))
+                    if len(tls[i]):
+                        bdoc, bsc, bc = bx.bm25_search(tls[i], k, allow_b)
+                        bl.append((bdoc[:bc], bsc[:bc]))
+                    else:
+                        bl.append((np.zeros(0, np.int64), np.zeros(0)))
+                # single legs
+                ids, sc, cnt = rank_batch([dict(index=di, weight=1.0, allow=allow_d, queries=q)], nq, k, 40, top_n, want_scores=True)
+                for i in range(nq):
+                    m = min(top_n, len(dl[i][0]))
+                    assert cnt[i] == m and ids[i, :m].tolist() == dl[i][0][:m].tolist(), ("rank dense ids", n, d, k, top_n, i)
+                    assert np.array_equal(sc[i, :m], dl[i][1][:m].astype(np.float64)), ("rank dense scores", n, d, k)
+                ids, sc, cnt = rank_batch([dict(index=bx, weight=1.0, allow=allow_b, term_lists=tls, doc_of_row=map_b)], nq, k, 40,
+                                          top_n, want_scores=True)
+                for i in range(nq):
+                    m = min(top_n, len(bl[i][0]))
+                    assert cnt[i] == m and ids[i, :m].tolist() == map_b[bl[i][0][:m]].tolist(), ("rank bm25 ids", nb, k, top_n, i)
+                    assert np.array_equal(sc[i, :m], bl[i][1][:m]), ("rank bm25 scores", nb, k)
+                # fusion of the two legs (+ the dense leg again under another weight and map: three lists)
+                three = rng.random() < 0.5
+                legs = [dict(index=di, weight=5.0, allow=allow_d, queries=q, doc_of_row=map_d),
+                        dict(index=bx, weight=1.0, allow=allow_b, term_lists=tls, doc_of_row=map_b)]
+                names = {"a": 5.0, "b": 1.0}
+                if three:
+                    map_c = rng.permutation(space)[:n].astype(np.int64)
+                    legs.insert(1, dict(index=di, weight=2.0, allow=allow_d, queries=q, doc_of_row=map_c))
+                    names["c"] = 2.0
+                if min(top_n, space, len(legs) * k) > cap64:
+                    top_n = cap64  # the fused order is cut to what one workgroup can sort (the call refuses beyond)
+                ids, sc, cnt = rank_batch(legs, nq, k, 40, top_n, id_space=space, want_scores=True)
+                for i in range(nq):
+                    lists = [(map_d[dl[i][0]].tolist(), "a")]
+                    if three:
+                        lists.append((map_c[dl[i][0]].tolist(), "c"))
+                    lists.append((map_b[bl[i][0]].tolist(), "b"))
+                    lists = [l for l in lists if l[0]]
+                    if len(lists) > 1:
+                        fused = ref_search.weighted_reciprocal_rank_fusion(lists, names, 40)[:top_n]
+                        assert cnt[i] == len(fused) and ids[i, :cnt[i]].tolist() == [x for x, _ in fused], ("rank fused ids", n, nb, k, top_n, i)
+                        assert sc[i, :cnt[i]].tolist() == [s_ for _, s_ in fused], ("rank fused scores", n, nb, k, i)
+                    elif len(lists) == 1:
+                        m = min(top_n, len(lists[0][0]))
+                        assert cnt[i] == m and ids[i, :m].tolist() == lists[0][0][:m], ("rank one list", n, nb, k, i)
+                    else:
+                        assert cnt[i] == 0
+                    checks += 1
+            # single dense queries on the scan lanes, interleaved with a group call and syncs
+            if d % 64 == 0:
+                import torch
+
+                dev = torch.device("cuda", 0)
+                nl = int(rng.integers(3, 40))
+                ql = np.ascontiguousarray(e[rng.integers(0, n, size=nl)] + 0.1 * rng.standard_normal((nl, d)).astype(np.float32))
+                Q = torch.from_numpy(ql).to(dev)
+                kk = int(rng.choice([1, 10, 64]))
+                out = torch.zeros((nl, kk, 2), dtype=torch.int64, device=dev)
+                torch.cuda.synchronize()
+                i = 0
+                while i < nl:
+                    g = 1 if rng.random() < 0.8 else int(min(nl - i, rng.integers(2, 12)))
+                    nat.check(lib.anrag_dense_search_device(di.handle, Q[i].data_ptr(), g, kk, None, out[i].data_ptr()))
+                    if rng.random() < 0.15:
+                        di.sync()
+                    i += g
+                di.sync()
+                got = out.cpu().numpy()
+                for i in range(nl):
+                    doc, sc_, c = di.dense_search(ql[i], kk)
+                    m = int(c[0])
+                    assert got[i, :m, 1].tolist() == doc[0, :m].tolist(), ("lane ids", n, d, kk, i)
+                    assert np.array_equal(got[i, :m, 0].copy().view(np.float64), sc_[0, :m].astype(np.float64)), ("lane scores", n, d, kk, i)
+                    checks += 1
+    print(f"rank fuzz ok: {rounds} corpora, {checks} checks in {budget:.0f} s (seed {seed})")
+    return checks
+
+
 if __name__ == "__main__":
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     if len(sys.argv) > 3 and sys.argv[3] == "big":
         run_big(budget, seed)
+    elif len(sys.argv) > 3 and sys.argv[3] == "rank":
+        run_rank(budget, seed)
     elif len(sys.argv) > 3 and sys.argv[3] == "batched":
         print("K2 fuzz ok:", run_batched(budget, seed), "query checks")
     else:

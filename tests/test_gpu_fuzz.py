@@ -30,3 +30,10 @@ def test_seeded_fuzz_of_bm25_on_large_partitions():
 def test_seeded_fuzz_of_the_batched_path():
     """65k .. 200k rows, 16 .. 300 queries per call, both K2 arithmetic modes, filters, ties, clustered corpora."""
     assert _fuzzer().run_batched(budget=25.0, seed=20262) >= 300
+
+
+def test_seeded_fuzz_of_the_full_ranking_lists_and_scan_lanes():
+    """`anrag_rank_batch` on corpora below / at / past the sort kernel's LDS capacity, ties at every cut, filters, 1-3 legs
+    with permuted document maps, against the per-query entry points (ids and score bits) and the reference's fusion; and
+    single dense queries on the scan lanes interleaved with group calls and syncs."""
+    assert _fuzzer().run_rank(budget=25.0, seed=20263) >= 60
