@@ -19,6 +19,7 @@
 //      asc) = Python's stable sort, and an emit kernel maps the winners back to document ids.
 // Nothing here is GEMM-shaped: HBM-bound score tiles, LDS-bound sorts.
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -137,6 +138,131 @@ template <int CAP>
 __device__ __forceinline__ void comp_load(const uint32_t *arr, int i, Comp<3> &c) {
     c.w0 = arr[i];
     c.k = ((uint64_t)arr[2 * CAP + i] << 32) | arr[CAP + i];
+}
+
+// Sort the m composites held in LDS (word w of entry i at arr[w * CAP + i]), best first.  All threads of the workgroup.
+template <int W, int CAP>
+__device__ __forceinline__ void lds_bitonic_sort(uint32_t *arr, int32_t m) {
+    constexpr int T = kRankThreads;
+    const int tid = threadIdx.x;
+    // bitonic network, best first, every comparator pointing the same way (a merge step starts with a "flip"):
+    // positions >= m stand for entries worse than all real ones, and since a comparator only ever moves the better
+    // entry DOWN in index they never move -- comparators that touch them are skipped, no padding is stored.
+    int32_t v2 = 2;
+    while (v2 < m) v2 <<= 1;
+    auto cmp_swap = [&](int32_t a, int32_t b) __attribute__((always_inline)) {
+        Comp<W> x, y;
+        comp_load<CAP>(arr, a, x);
+        comp_load<CAP>(arr, b, y);
+        if (comp_gt(y, x)) {
+            comp_store<CAP>(arr, a, y);
+            comp_store<CAP>(arr, b, x);
+        }
+    };
+    const int32_t half_all = v2 >> 1;
+    auto flip_stage = [&](int32_t size, int lg_half) __attribute__((always_inline)) {
+        const int32_t half = size >> 1;
+        for (int32_t c = tid; c < half_all; c += T) {
+            const int32_t blk = c >> lg_half, t = c & (half - 1);
+            const int32_t a = blk * size + t, b = blk * size + size - 1 - t;
+            if (b < m) cmp_swap(a, b);
+        }
+        __syncthreads();
+    };
+    auto stride_stage = [&](int32_t stride) __attribute__((always_inline)) {
+        for (int32_t c = tid; c < half_all; c += T) {
+            const int32_t a = ((c & ~(stride - 1)) << 1) | (c & (stride - 1)), b = a + stride;
+            if (b < m) cmp_swap(a, b);
+        }
+        __syncthreads();
+    };
+    // The stages whose partners are < 16 apart stay in REGISTERS: a thread takes a block of 16 consecutive entries (four
+    // 16-byte LDS reads per word array), runs the stages on them, writes the block back -- one LDS round trip for the
+    // four stages (strides 8, 4, 2, 1) that end every merge, and for the whole of the first four merges: 66 instead of
+    // 105 rounds at 16,384 entries.  Entries past m are read as the worst composite (all zero) and written back as such:
+    // they never move (a comparator only moves the better entry down in index) and nobody else reads them.
+    constexpr int LB = 16;
+    auto local_round = [&](int32_t from_size) __attribute__((always_inline)) {  // from_size: 2 = the merges of 2..16; 0 = strides 8..1
+        const int32_t n_blocks = (m + LB - 1) / LB;
+        static_assert(CAP <= LB * T, "one register block per thread covers the array");
+        if (const int32_t blk = tid; blk < n_blocks) {  // (a loop here was unrolled by two in one kernel: 38 spills)
+            Comp<W> x[LB];
+            uint32_t word[W][LB];
+#pragma unroll
+            for (int w = 0; w < W; ++w)
+#pragma unroll
+                for (int c = 0; c < LB / 4; ++c) {
+                    const uint4 v = *reinterpret_cast<const uint4 *>(&arr[w * CAP + blk * LB + 4 * c]);
+                    word[w][4 * c] = v.x;
+                    word[w][4 * c + 1] = v.y;
+                    word[w][4 * c + 2] = v.z;
+                    word[w][4 * c + 3] = v.w;
+                }
+#pragma unroll
+            for (int i = 0; i < LB; ++i) {
+                const bool real = blk * LB + i < m;
+                if constexpr (W == 2) x[i] = Comp<2>{real ? word[0][i] : 0u, real ? word[1][i] : 0u};
+                else x[i] = Comp<3>{real ? word[0][i] : 0u, real ? (((uint64_t)word[2][i] << 32) | word[1][i]) : 0ull};
+            }
+            auto cx = [&](int a, int b) __attribute__((always_inline)) {
+                if (comp_gt(x[b], x[a])) {
+                    const Comp<W> t = x[a];
+                    x[a] = x[b];
+                    x[b] = t;
+                }
+            };
+            if (from_size == 2) {
+#pragma unroll
+                for (int size = 2; size <= LB; size <<= 1) {
+#pragma unroll
+                    for (int i = 0; i < LB; ++i)
+                        if ((i & (size - 1)) < size / 2) cx(i, (i & ~(size - 1)) + size - 1 - (i & (size - 1)));
+#pragma unroll
+                    for (int stride = size / 4; stride >= 1; stride >>= 1)
+#pragma unroll
+                        for (int i = 0; i < LB; ++i)
+                            if (!(i & stride)) cx(i, i + stride);
+                }
+            } else {
+#pragma unroll
+                for (int stride = LB / 2; stride >= 1; stride >>= 1)
+#pragma unroll
+                    for (int i = 0; i < LB; ++i)
+                        if (!(i & stride)) cx(i, i + stride);
+            }
+#pragma unroll
+            for (int w = 0; w < W; ++w)
+#pragma unroll
+                for (int c = 0; c < LB / 4; ++c) {
+                    uint4 v;
+                    auto wd = [&](int i) __attribute__((always_inline)) -> uint32_t {
+                        if constexpr (W == 2) return w == 0 ? x[i].w0 : x[i].w1;
+                        else return w == 0 ? x[i].w0 : (w == 1 ? (uint32_t)x[i].k : (uint32_t)(x[i].k >> 32));
+                    };
+                    v.x = wd(4 * c);
+                    v.y = wd(4 * c + 1);
+                    v.z = wd(4 * c + 2);
+                    v.w = wd(4 * c + 3);
+                    *reinterpret_cast<uint4 *>(&arr[w * CAP + blk * LB + 4 * c]) = v;
+                }
+        }
+        __syncthreads();
+    };
+    if (v2 >= 2 * LB) {
+        local_round(2);  // every block of 16 sorted
+        int lg_half = 4;
+        for (int32_t size = 2 * LB; size <= v2; size <<= 1, ++lg_half) {
+            flip_stage(size, lg_half);
+            for (int32_t stride = size >> 2; stride >= LB; stride >>= 1) stride_stage(stride);
+            local_round(0);
+        }
+    } else {  // a handful of entries: the plain network
+        int lg_half = 0;
+        for (int32_t size = 2; size <= v2; size <<= 1, ++lg_half) {
+            flip_stage(size, lg_half);
+            for (int32_t stride = size >> 2; stride >= 1; stride >>= 1) stride_stage(stride);
+        }
+    }
 }
 
 // ------------------------------------------------------------------ select + sort, one workgroup per segment
@@ -292,123 +418,7 @@ __global__ __launch_bounds__(kRankThreads) void seg_topk_sort_kernel(
     const int32_t m = (int32_t)(ctrl[0] < (uint32_t)CAP ? ctrl[0] : (uint32_t)CAP);
     if (k_eff > m) k_eff = m;  // n <= CAP: everything that is a candidate
 
-    // bitonic network, best first, every comparator pointing the same way (a merge step starts with a "flip"):
-    // positions >= m stand for entries worse than all real ones, and since a comparator only ever moves the better
-    // entry DOWN in index they never move -- comparators that touch them are skipped, no padding is stored.
-    int32_t v2 = 2;
-    while (v2 < m) v2 <<= 1;
-    auto cmp_swap = [&](int32_t a, int32_t b) __attribute__((always_inline)) {
-        Comp<W> x, y;
-        comp_load<CAP>(arr, a, x);
-        comp_load<CAP>(arr, b, y);
-        if (comp_gt(y, x)) {
-            comp_store<CAP>(arr, a, y);
-            comp_store<CAP>(arr, b, x);
-        }
-    };
-    const int32_t half_all = v2 >> 1;
-    auto flip_stage = [&](int32_t size, int lg_half) __attribute__((always_inline)) {
-        const int32_t half = size >> 1;
-        for (int32_t c = tid; c < half_all; c += T) {
-            const int32_t blk = c >> lg_half, t = c & (half - 1);
-            const int32_t a = blk * size + t, b = blk * size + size - 1 - t;
-            if (b < m) cmp_swap(a, b);
-        }
-        __syncthreads();
-    };
-    auto stride_stage = [&](int32_t stride) __attribute__((always_inline)) {
-        for (int32_t c = tid; c < half_all; c += T) {
-            const int32_t a = ((c & ~(stride - 1)) << 1) | (c & (stride - 1)), b = a + stride;
-            if (b < m) cmp_swap(a, b);
-        }
-        __syncthreads();
-    };
-    // The stages whose partners are < 16 apart stay in REGISTERS: a thread takes a block of 16 consecutive entries (four
-    // 16-byte LDS reads per word array), runs the stages on them, writes the block back -- one LDS round trip for the
-    // four stages (strides 8, 4, 2, 1) that end every merge, and for the whole of the first four merges: 66 instead of
-    // 105 rounds at 16,384 entries.  Entries past m are read as the worst composite (all zero) and written back as such:
-    // they never move (a comparator only moves the better entry down in index) and nobody else reads them.
-    constexpr int LB = 16;
-    auto local_round = [&](int32_t from_size) __attribute__((always_inline)) {  // from_size: 2 = the merges of 2..16; 0 = strides 8..1
-        const int32_t n_blocks = (m + LB - 1) / LB;
-        for (int32_t blk = tid; blk < n_blocks; blk += T) {
-            Comp<W> x[LB];
-            uint32_t word[W][LB];
-#pragma unroll
-            for (int w = 0; w < W; ++w)
-#pragma unroll
-                for (int c = 0; c < LB / 4; ++c) {
-                    const uint4 v = *reinterpret_cast<const uint4 *>(&arr[w * CAP + blk * LB + 4 * c]);
-                    word[w][4 * c] = v.x;
-                    word[w][4 * c + 1] = v.y;
-                    word[w][4 * c + 2] = v.z;
-                    word[w][4 * c + 3] = v.w;
-                }
-#pragma unroll
-            for (int i = 0; i < LB; ++i) {
-                const bool real = blk * LB + i < m;
-                if constexpr (W == 2) x[i] = Comp<2>{real ? word[0][i] : 0u, real ? word[1][i] : 0u};
-                else x[i] = Comp<3>{real ? word[0][i] : 0u, real ? (((uint64_t)word[2][i] << 32) | word[1][i]) : 0ull};
-            }
-            auto cx = [&](int a, int b) __attribute__((always_inline)) {
-                if (comp_gt(x[b], x[a])) {
-                    const Comp<W> t = x[a];
-                    x[a] = x[b];
-                    x[b] = t;
-                }
-            };
-            if (from_size == 2) {
-#pragma unroll
-                for (int size = 2; size <= LB; size <<= 1) {
-#pragma unroll
-                    for (int i = 0; i < LB; ++i)
-                        if ((i & (size - 1)) < size / 2) cx(i, (i & ~(size - 1)) + size - 1 - (i & (size - 1)));
-#pragma unroll
-                    for (int stride = size / 4; stride >= 1; stride >>= 1)
-#pragma unroll
-                        for (int i = 0; i < LB; ++i)
-                            if (!(i & stride)) cx(i, i + stride);
-                }
-            } else {
-#pragma unroll
-                for (int stride = LB / 2; stride >= 1; stride >>= 1)
-#pragma unroll
-                    for (int i = 0; i < LB; ++i)
-                        if (!(i & stride)) cx(i, i + stride);
-            }
-#pragma unroll
-            for (int w = 0; w < W; ++w)
-#pragma unroll
-                for (int c = 0; c < LB / 4; ++c) {
-                    uint4 v;
-                    auto wd = [&](int i) __attribute__((always_inline)) -> uint32_t {
-                        if constexpr (W == 2) return w == 0 ? x[i].w0 : x[i].w1;
-                        else return w == 0 ? x[i].w0 : (w == 1 ? (uint32_t)x[i].k : (uint32_t)(x[i].k >> 32));
-                    };
-                    v.x = wd(4 * c);
-                    v.y = wd(4 * c + 1);
-                    v.z = wd(4 * c + 2);
-                    v.w = wd(4 * c + 3);
-                    *reinterpret_cast<uint4 *>(&arr[w * CAP + blk * LB + 4 * c]) = v;
-                }
-        }
-        __syncthreads();
-    };
-    if (v2 >= 2 * LB) {
-        local_round(2);  // every block of 16 sorted
-        int lg_half = 4;
-        for (int32_t size = 2 * LB; size <= v2; size <<= 1, ++lg_half) {
-            flip_stage(size, lg_half);
-            for (int32_t stride = size >> 2; stride >= LB; stride >>= 1) stride_stage(stride);
-            local_round(0);
-        }
-    } else {  // a handful of entries: the plain network
-        int lg_half = 0;
-        for (int32_t size = 2; size <= v2; size <<= 1, ++lg_half) {
-            flip_stage(size, lg_half);
-            for (int32_t stride = size >> 2; stride >= 1; stride >>= 1) stride_stage(stride);
-        }
-    }
+    lds_bitonic_sort<W, CAP>(arr, m);
 
     for (int32_t i = tid; i < k_eff; i += T) {
         out_tie[seg * out_stride + i] = ~arr[i];
@@ -511,6 +521,98 @@ __global__ __launch_bounds__(256) void rank_emit_single_kernel(const uint32_t *_
     if (i == 0) out_cnt[q] = c;
 }
 
+// Fusion of an id space that fits the LDS, ONE workgroup per query, one launch for everything behind the legs' lists:
+// the fp64 sums and the insertion keys live in LDS while the legs are added in order (a barrier between legs: a leg names
+// a document once, so its adds do not collide, and legs follow each other = the reference's dict update order), are
+// turned into composites in place, sorted by the network above, and the winners are mapped back to document ids -- no
+// F / T arrays in HBM, no fill, accumulate or emit launches (they were 0.7 of the 6.3 us per query at 9,609 documents).
+
+// (the leg table is read from HBM as a flat array of 64-bit words, field f of leg l at tab[f * 16 + l]: it is indexed per
+// lane in the emit, and a struct -- by value or behind a pointer -- was copied to scratch for that: 1.2 KB, 2,087 spills)
+__global__ __launch_bounds__(kRankThreads) void rank_fuse_sort_kernel(const uint64_t *tab, double wrrf_k, int32_t id_space,
+                                                                      int32_t out_n, int64_t *__restrict__ out_id,
+                                                                      double *__restrict__ out_score,
+                                                                      int32_t *__restrict__ out_cnt,
+                                                                      const int64_t *__restrict__ expect,
+                                                                      int32_t *__restrict__ out_rank) {
+    constexpr int W = 3, CAP = rank_cap<3>(), T = kRankThreads;
+    extern __shared__ __attribute__((aligned(16))) uint32_t rank_lds[];
+    uint32_t *ctrl = rank_lds;
+    uint32_t *arr = rank_lds + kRankCtrlWords;
+    uint32_t *tie = arr;  // word 0 of the composites: ~(insertion key), 0 = no list names it
+    // while the legs are added, words 1 and 2 hold the raw bits of the fp64 sums (already in the composites' layout, so
+    // the turn to order-preserving key bits is element-wise and in place)
+    auto get_sum = [&](int32_t d) __attribute__((always_inline)) {
+        return __longlong_as_double((long long)(((uint64_t)arr[2 * CAP + d] << 32) | arr[CAP + d]));
+    };
+    auto put_bits = [&](int32_t d, uint64_t b) __attribute__((always_inline)) {
+        arr[CAP + d] = (uint32_t)b;
+        arr[2 * CAP + d] = (uint32_t)(b >> 32);
+    };
+    const int tid = threadIdx.x, lane = tid & (kWave - 1);
+    const int64_t q = blockIdx.x;
+    constexpr int M = ANRAG_WRRF_MAX_LISTS;
+    auto leg_rows = [&](uint32_t l) __attribute__((always_inline)) { return reinterpret_cast<const uint32_t *>(tab[l]) + q * (int64_t)tab[3 * M + l]; };
+    auto leg_map = [&](uint32_t l) __attribute__((always_inline)) { return reinterpret_cast<const int32_t *>(tab[2 * M + l]); };
+    for (int32_t i = tid; i < id_space; i += T) tie[i] = 0u;
+    if (tid == 0) ctrl[0] = 0;
+    __syncthreads();
+    const int n_legs = (int)tab[5 * M];
+#pragma unroll 1
+    for (int l = 0; l < n_legs; ++l) {
+        const int32_t n = reinterpret_cast<const int32_t *>(tab[M + l])[q];
+        const uint32_t *rows = leg_rows(l);
+        const int32_t *map = leg_map(l);
+        const double w = __longlong_as_double((long long)tab[4 * M + l]);
+        for (int32_t p = tid; p < n; p += T) {
+            const uint32_t row = rows[p];
+            const int32_t d = map ? map[row] : (int32_t)row;
+            const double c = w * (1.0 / (wrrf_k + (double)(p + 1)));  // src/search_engine.py:30, rank from 1
+            if (tie[d] == 0u) {
+                put_bits(d, (uint64_t)__double_as_longlong(0.0 + c));  // `rrf_scores[doc_id] = 0`, then `+=`
+                tie[d] = ~(((uint32_t)l << kTiePosBits) | (uint32_t)p);
+            } else {
+                put_bits(d, (uint64_t)__double_as_longlong(get_sum(d) + c));
+            }
+        }
+        __syncthreads();
+    }
+    // sums -> order-preserving key bits; a document no list names becomes the all-zero composite, the worst there is
+    int32_t named = 0;
+    for (int32_t i = tid; i < id_space; i += T) {
+        uint64_t b = 0;
+        if (tie[i] != 0u) {
+            b = order_bits(get_sum(i));
+            ++named;
+        }
+        put_bits(i, b);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) named += __shfl_xor(named, off, kWave);
+    if (lane == 0 && named) atomicAdd(&ctrl[0], (uint32_t)named);
+    __syncthreads();
+    lds_bitonic_sort<W, CAP>(arr, id_space);
+    const int32_t qe = (int32_t)blockIdx.x, out_ne = out_n;
+    const int32_t n_named = (int32_t)ctrl[0];
+    const int32_t k_out = n_named < out_ne ? n_named : out_ne;
+    for (int32_t i = tid; i < out_ne; i += T) {
+        int64_t id = -1;
+        double sc = -__builtin_huge_val();
+        if (i < k_out) {
+            const uint32_t t = ~arr[i];
+            const uint32_t l = t >> kTiePosBits, p = t & ((1u << kTiePosBits) - 1u);
+            const uint32_t row = (reinterpret_cast<const uint32_t *>(tab[l]) + (int64_t)qe * (int64_t)tab[3 * M + l])[p];
+            const int32_t *map = leg_map(l);
+            id = map ? (int64_t)map[row] : (int64_t)row;
+            sc = unorder_bits(((uint64_t)arr[2 * CAP + i] << 32) | arr[CAP + i]);
+            if (expect && id == expect[qe]) out_rank[qe] = i + 1;
+        }
+        out_id[(int64_t)qe * out_ne + i] = id;
+        out_score[(int64_t)qe * out_ne + i] = sc;
+    }
+    if (tid == 0) out_cnt[qe] = k_out;
+}
+
 template <typename KEY, bool TIE>
 static int launch_seg_sort(int device, hipStream_t st, int32_t n_seg, const KEY *keys, int64_t key_stride,
                            const uint32_t *ties, int64_t tie_stride, int32_t n, int32_t k, const int32_t *seg_k,
@@ -599,12 +701,14 @@ extern "C" int anrag_rank_batch(const anrag_rank_leg *legs, int32_t n_legs, int3
         ANRAG_REQUIRE(leg_k[l] < (1 << kTiePosBits), "leg %d: list too long", l);
         sum_k += leg_k[l];
     }
+    bool fuse_in_lds = false;  // the id space fits one workgroup's LDS: rank_fuse_sort_kernel does the whole fusion
     int32_t fuse_n = 0;  // entries the fused order is cut to
     if (fuse) {
         ANRAG_REQUIRE(id_space > 0 && id_space < 0x7FFFFFFFll, "id_space %lld out of range", (long long)id_space);
         fuse_n = (int32_t)std::min<int64_t>(std::min<int64_t>(top_n, sum_k), id_space);
         ANRAG_REQUIRE(fuse_n <= rank_cap<3>(), "min(top_n, entries) = %d is outside the batched ranking's envelope (%d)",
                       fuse_n, rank_cap<3>());
+        fuse_in_lds = id_space <= rank_cap<3>() && !getenv("ANRAG_RANK_FUSE_IN_HBM");
         // a leg must name a document once and inside the id space: the additions of a document then happen in leg
         // order whatever the thread schedule (rank_accumulate_kernel)
         std::vector<uint64_t> seen((size_t)((id_space + 63) / 64));
@@ -638,7 +742,9 @@ extern "C" int anrag_rank_batch(const anrag_rank_leg *legs, int32_t n_legs, int3
         per_query += dense ? (int64_t)legs[l].idx->dim * 4 : 0;
         fixed += 2048 * 4 + 256 + (legs[l].doc_of_row ? leg_rows[l] * 4 + 256 : 0);
     }
-    if (fuse) per_query += id_space * 12 + 512 + (int64_t)fuse_n * 12 + 512 + 4;
+    if (fuse && !fuse_in_lds) per_query += id_space * 12 + 512 + (int64_t)fuse_n * 12 + 512 + 4;
+    if (fuse) per_query += 4 + 256;
+    fixed += 1024;
     per_query += (int64_t)out_n * 16 + 4 + 512 + 16;
     int64_t max_terms_chunk = 0;  // sized below, once the chunk is known
     const int64_t budget = 6ll << 30;
@@ -703,13 +809,14 @@ extern "C" int anrag_rank_batch(const anrag_rank_leg *legs, int32_t n_legs, int3
     double *d_f = nullptr, *d_skey = nullptr;
     uint32_t *d_t = nullptr, *d_stie = nullptr;
     int32_t *d_scnt = nullptr;
-    if (fuse) {
+    if (fuse && !fuse_in_lds) {
         d_f = cv.take<double>(chunk * id_space);
         d_t = cv.take<uint32_t>(chunk * id_space);
         d_stie = cv.take<uint32_t>(chunk * fuse_n);
         d_skey = cv.take<double>(chunk * fuse_n);
-        d_scnt = cv.take<int32_t>(chunk);
     }
+    if (fuse) d_scnt = cv.take<int32_t>(chunk);
+    uint64_t *d_fuse_legs = fuse_in_lds ? cv.take<uint64_t>(6 * ANRAG_WRRF_MAX_LISTS) : nullptr;
     int64_t *d_out_id = cv.take<int64_t>(chunk * out_n);
     double *d_out_score = cv.take<double>(chunk * out_n);
     int32_t *d_out_cnt = fuse ? d_scnt : cv.take<int32_t>(chunk);
@@ -720,6 +827,20 @@ extern "C" int anrag_rank_batch(const anrag_rank_leg *legs, int32_t n_legs, int3
         return ANRAG_ERR_STATE;
     }
 
+    if (fuse_in_lds) {  // the legs' lists, counts, maps, strides and weights: the same for every chunk
+        constexpr int M = ANRAG_WRRF_MAX_LISTS;
+        uint64_t tab[6 * M] = {};
+        for (int l = 0; l < n_legs; ++l) {
+            tab[l] = reinterpret_cast<uint64_t>(ld[l].rows);
+            tab[M + l] = reinterpret_cast<uint64_t>(ld[l].cnt);
+            tab[2 * M + l] = reinterpret_cast<uint64_t>(ld[l].doc_of_row);
+            tab[3 * M + l] = (uint64_t)leg_k[l];
+            memcpy(&tab[4 * M + l], &legs[l].weight, 8);
+        }
+        tab[5 * M] = (uint64_t)n_legs;
+        ANRAG_HIP(hipMemcpyAsync(d_fuse_legs, tab, sizeof(tab), hipMemcpyHostToDevice, st));
+        ANRAG_HIP(hipStreamSynchronize(st));
+    }
     std::vector<int32_t> h_segk;
     for (int64_t q0 = 0; q0 < n_queries; q0 += chunk) {
         const int32_t c = (int32_t)std::min<int64_t>(chunk, n_queries - q0);
@@ -786,7 +907,13 @@ extern "C" int anrag_rank_batch(const anrag_rank_leg *legs, int32_t n_legs, int3
                     return rc;
             }
         }
-        if (fuse) {
+        if (fuse && fuse_in_lds) {
+            if ((rc = ensure_dynamic_lds(device, reinterpret_cast<const void *>(&rank_fuse_sort_kernel), rank_lds_bytes<3>())))
+                return rc;
+            rank_fuse_sort_kernel<<<c, kRankThreads, rank_lds_bytes<3>(), st>>>(d_fuse_legs, wrrf_k, (int32_t)id_space, out_n,
+                                                                                d_out_id, d_out_score, d_out_cnt, d_expect,
+                                                                                d_rank);
+        } else if (fuse) {
             const int64_t total = (int64_t)c * id_space;
             rank_fill_kernel<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(d_f, d_t, total);
             RankLegsDev L;

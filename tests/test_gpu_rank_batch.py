@@ -1,6 +1,8 @@
 """GPU parity: `anrag_rank_batch` -- full ranking (similarity_k = 12,000, src/retrieval_eval.py:142-143) for lists of
 queries on the device -- against the oracle (numpy restatement of src/search_engine.py), against the per-query entry
 points (same ids, same score bits) and, for the fusion, bit for bit against the reference's dict + stable sort."""
+import os
+
 import numpy as np
 import pytest
 
@@ -134,6 +136,14 @@ def test_fused_matches_reference_fusion_bitwise(c1, flt, k, top_n):
                 dict(index=d2, weight=2.0, allow=ad2, queries=q2, doc_of_row=perm),
                 dict(index=w["bx"], weight=1.0, allow=ab, term_lists=term_lists, doc_of_row=w["ids_b"])]
         ids, sc, cnt = rank_batch(legs, nq, k, 40, top_n, id_space=w["id_space"], want_scores=True)
+        # an id space of 9,609 is fused inside one workgroup's LDS (rank_fuse_sort_kernel); the route larger id spaces
+        # take (sums in HBM: fill, accumulate per leg, sort, emit) must give the same bits
+        os.environ["ANRAG_RANK_FUSE_IN_HBM"] = "1"
+        try:
+            ids_h, sc_h, cnt_h = rank_batch(legs, nq, k, 40, top_n, id_space=w["id_space"], want_scores=True)
+        finally:
+            del os.environ["ANRAG_RANK_FUSE_IN_HBM"]
+        assert np.array_equal(ids, ids_h) and np.array_equal(cnt, cnt_h) and np.array_equal(sc.view(np.int64), sc_h.view(np.int64))
         for i in range(nq):
             l1, _, c1_ = w["di"].dense_search(w["q"][i], k, ad)
             l2, _, c2_ = d2.dense_search(q2[i], k, ad2)
