@@ -855,7 +855,13 @@ extern "C" int anrag_rank_batch(const anrag_rank_leg *legs, int32_t n_legs, int3
                 ANRAG_HIP(hipMemcpyAsync(ld[l].q, g.queries + q0 * ix->dim, (size_t)c * ix->dim * sizeof(float),
                                          hipMemcpyHostToDevice, st));
                 float *tile = static_cast<float *>(ld[l].scores);
-                for (int32_t g0 = 0; g0 < c; g0 += kScanGroupMax) {
+                const int tile_n = getenv("ANRAG_RANK_SCAN_TILES") ? 0 : dense_tile_group_max(ix);
+                for (int32_t g0 = 0; tile_n > 0 && g0 < c; g0 += kTileLaunchMax)  // K1T: the rows once per tile_n queries
+                    if ((rc = launch_dense_tile(ix, st, ld[l].q + (int64_t)g0 * ix->dim, ix->dim,
+                                                std::min<int32_t>(kTileLaunchMax, c - g0), ld[l].allow,
+                                                tile + (int64_t)g0 * ld[l].stride, ld[l].stride)))
+                        return rc;
+                for (int32_t g0 = tile_n > 0 ? c : 0; g0 < c; g0 += kScanGroupMax) {  // other dimensions: a pass per query
                     const int n = std::min<int32_t>(kScanGroupMax, c - g0);
                     const float *qs[kScanGroupMax];
                     int sets[kScanGroupMax];

@@ -184,6 +184,37 @@ def test_expected_rank_equals_position_in_the_list(c1):
             assert ranks[i] == (pos[0] + 1 if len(pos) else -1), (i, k, top_n)
 
 
+@pytest.mark.parametrize("d", [64, 128, 192, 256, 320, 384, 448, 512, 640, 768, 896, 1024, 1536, 2048, 3072, 8])
+def test_score_tiles_equal_the_scan_scores_at_every_kernel_shape(d):
+    """K1T (dense_tile.hip: a batch of rows in registers, all the queries of a launch over it) against K1's own score
+    pass for one query (`dense_scores`), bit for bit, at every dimension with a shaped kernel (3,072: no tile kernel, a
+    pass per query; 8: the generic kernel), corpora from one row to a few per wave to many, 19 queries (one launch takes
+    16 at most, 6 at 2,048-d), with and without a source filter."""
+    from oracle import ref_search
+    from anrag.index import Index, rank_batch
+
+    rng = np.random.default_rng(d)
+    nq = 19
+    for n in (1, 3, 63, 1000, 5003):
+        e = rng.standard_normal((n, d), dtype=np.float32)
+        if n > 10:
+            e[n // 2] = e[1]
+            e[7] = np.nan if d == 384 else e[7]  # a NaN row ranks first (numpy's order): carried as +inf
+        q = rng.standard_normal((nq, d), dtype=np.float32)
+        sid = (np.arange(n) % 5).astype(np.uint16)
+        allow = np.array([1, 0, 1, 1, 0], np.uint8)
+        with Index(0) as di:
+            di.dense_load(e, source_id=sid)
+            for al in (None, allow):
+                ids, sc, cnt = rank_batch([dict(index=di, weight=1.0, allow=al, queries=q)], nq, n, 40, n, want_scores=True)
+                ok = None if al is None else al.astype(bool)[sid]
+                for i in range(nq):
+                    full = di.dense_scores(q[i])
+                    want = ref_search.canonical_topk(full, n, ok)
+                    assert cnt[i] == len(want) and ids[i, :cnt[i]].tolist() == want.tolist(), (d, n, i)
+                    assert np.array_equal(sc[i, :cnt[i]], full[want].astype(np.float64)), (d, n, i)
+
+
 def test_select_path_heavy_ties_and_edges():
     """Segments longer than a workgroup's LDS (the radix select runs first): all-equal scores (every BM25 score 0: the
     k lowest rows win), duplicated rows, k = 1, a segment one element past the cap, a filter that keeps fewer than k."""
