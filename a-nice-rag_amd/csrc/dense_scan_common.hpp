@@ -6,6 +6,7 @@
 namespace anrag {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));  // native vector: global_load_dwordx4, nt-loadable
+typedef float f32x2 __attribute__((ext_vector_type(2)));  // a 64-bit register pair: v_pk_fma_f32's operands
 
 __device__ __forceinline__ float dot4(f32x4 a, f32x4 b, float acc) {
     acc = __builtin_fmaf(a.x, b.x, acc);

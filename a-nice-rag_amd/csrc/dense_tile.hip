@@ -5,6 +5,9 @@
 #include "wave_topk.hpp"
 #include "dense_scan_common.hpp"
 
+// (m0 carries v_writelane's lane select below: nothing else in this file uses it -- no LDS-DMA, no s_movrel, no messages)
+#pragma clang diagnostic ignored "-Winline-asm"
+
 namespace anrag {
 
 // K1T -- score TILES for lists of queries (rank_batch.hip: full ranking, src/retrieval_eval.py:142-143): every score of n
@@ -24,7 +27,74 @@ constexpr int kTileGroupMax = 16;  // queries per launch: 16 parking registers; 
 // queries in LDS at a time: 16 parking registers at most, and n * dim * 4 <= 48 KB (+ 8 KB of filter bits: inside the
 // 64 KB a launch gets without asking), dim = 4 * G * CH
 template <int G, int CH>
-constexpr int tile_group() { return 3072 / (G * CH) < kTileGroupMax ? 3072 / (G * CH) : kTileGroupMax; }
+constexpr int tile_group() { return (3072 / (G * CH) < kTileGroupMax ? 3072 / (G * CH) : kTileGroupMax) & ~1; }  // pairs
+
+// group_sum (dense_scan_common.hpp) with its two row_bcast steps as ONE instruction each.  The compiler turns
+// `v + update_dpp(0, v, row_bcast, row_mask)` into v_mov 0 / v_mov_dpp / v_add (it has no identity fold for float adds under
+// a partial row mask); `v_add_f32_dpp v, v, v row_bcast:15 row_mask:0xa` is the same sum in the rows the mask enables and
+// leaves the others alone -- same operands, same rounding, 4 instructions fewer per reduced value.  (The s_nops: a DPP read
+// of a VGPR needs two wait states behind the VALU write, a v_readlane one; the hazard recognizer does not look inside asm.)
+template <int G>
+__device__ __forceinline__ float tile_group_sum(float v) {
+    if constexpr (G >= 2) v = dpp_add<0xB1, 0xF>(v);
+    if constexpr (G >= 4) v = dpp_add<0x4E, 0xF>(v);
+    if constexpr (G >= 8) v = dpp_add<0x141, 0xF>(v);
+    if constexpr (G >= 16) v = dpp_add<0x140, 0xF>(v);
+    if constexpr (G == 32)
+        asm("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\ts_nop 0" : "+v"(v));
+    if constexpr (G == 64)
+        asm("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+            "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\ts_nop 0"
+            : "+v"(v));
+    return v;
+}
+
+// ... of N independent values, step by step across all of them (N - 1 instructions between a write and the DPP read of it:
+// no wait states to pad when N >= 3).  Same tree per value.
+template <int G, int N>
+__device__ __forceinline__ void tile_group_sums(float (&v)[N]) {
+    if constexpr (N != 4 && N != 2) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) v[j] = tile_group_sum<G>(v[j]);
+    } else {
+#define ANRAG_STEP(CTRL)                                      \
+    _Pragma("unroll") for (int j = 0; j < N; ++j) v[j] = dpp_add<CTRL, 0xF>(v[j]);
+        if constexpr (G >= 2) { ANRAG_STEP(0xB1) }
+        if constexpr (G >= 4) { ANRAG_STEP(0x4E) }
+        if constexpr (G >= 8) { ANRAG_STEP(0x141) }
+        if constexpr (G >= 16) { ANRAG_STEP(0x140) }
+#undef ANRAG_STEP
+        if constexpr (N == 4) {
+            if constexpr (G >= 32)
+                asm("s_nop 1\n\t"
+                    "v_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                    "v_add_f32_dpp %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                    "v_add_f32_dpp %2, %2, %2 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                    "v_add_f32_dpp %3, %3, %3 row_bcast:15 row_mask:0xa bank_mask:0xf"
+                    : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]));
+            if constexpr (G >= 64)
+                asm("v_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+                    "v_add_f32_dpp %1, %1, %1 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+                    "v_add_f32_dpp %2, %2, %2 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+                    "v_add_f32_dpp %3, %3, %3 row_bcast:31 row_mask:0xc bank_mask:0xf"
+                    : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]));
+            if constexpr (G >= 32) asm volatile("s_nop 0" ::: "memory");  // v_readlane behind a VALU write
+        } else {
+            if constexpr (G >= 32)
+                asm("s_nop 1\n\t"
+                    "v_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                    "v_add_f32_dpp %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                    "s_nop 0"
+                    : "+v"(v[0]), "+v"(v[1]));
+            if constexpr (G >= 64)
+                asm("s_nop 0\n\t"
+                    "v_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+                    "v_add_f32_dpp %1, %1, %1 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+                    "s_nop 0"
+                    : "+v"(v[0]), "+v"(v[1]));
+        }
+    }
+}
 
 template <int CH>
 constexpr int tile_r() { return CH >= 6 ? 1 : (CH >= 3 ? 2 : (CH == 2 ? 4 : 8)); }  // a power of two: 64 % (R * GROUPS) == 0
@@ -35,6 +105,7 @@ __global__ __launch_bounds__(kScanThreads) void dense_tile_kernel(
     int64_t n_rows, int32_t dim, const uint16_t *__restrict__ src, const uint32_t *__restrict__ allow_bits,
     float *__restrict__ scores_out, int64_t scores_stride) {
     constexpr int GROUPS = kWave / G, RW = GROUPS * R, NQ = tile_group<G, CH>();
+    static_assert(NQ >= 2 && NQ % 2 == 0, "the queries of a group are computed in pairs");
     static_assert(kWave % RW == 0, "a parked block of 64 scores ends at a batch boundary");
     extern __shared__ __attribute__((aligned(16))) float tile_lds[];
     __shared__ uint32_t lds_allow[FILTER ? 2048 : 1];
@@ -75,9 +146,17 @@ __global__ __launch_bounds__(kScanThreads) void dense_tile_kernel(
     for (int32_t g0 = 0; g0 < n_q; g0 += NQ) {
         const int32_t n_g = n_q - g0 < NQ ? n_q - g0 : NQ;
         if (g0 > 0) __syncthreads();  // every wave is done with the previous group's slices
-        for (int32_t i = 0; i < n_g; ++i) {
-            const f32x4 *qv = reinterpret_cast<const f32x4 *>(queries + (int64_t)(g0 + i) * q_stride);
-            for (int32_t j = threadIdx.x; j < row_f4; j += kScanThreads) q_lds[i * row_f4 + j] = qv[j];
+        // queries in PAIRS, element-interleaved: float4 j of queries (A, B) as (A.x, B.x, A.y, B.y) at [j] and
+        // (A.z, B.z, A.w, B.w) at [row_f4 + j] of the pair's block -- the operand layout of the packed FMAs below
+        for (int32_t p = 0; 2 * p < n_g; ++p) {
+            const int32_t ia = g0 + 2 * p, ib = 2 * p + 1 < n_g ? ia + 1 : ia;  // an odd group's last pair: (A, A)
+            const f32x4 *qa = reinterpret_cast<const f32x4 *>(queries + (int64_t)ia * q_stride);
+            const f32x4 *qb = reinterpret_cast<const f32x4 *>(queries + (int64_t)ib * q_stride);
+            for (int32_t j = threadIdx.x; j < row_f4; j += kScanThreads) {
+                const f32x4 a = qa[j], b = qb[j];
+                q_lds[2 * p * row_f4 + j] = f32x4{a.x, b.x, a.y, b.y};
+                q_lds[(2 * p + 1) * row_f4 + j] = f32x4{a.z, b.z, a.w, b.w};
+            }
         }
         __syncthreads();
         if (!has_rows) continue;
@@ -90,43 +169,100 @@ __global__ __launch_bounds__(kScanThreads) void dense_tile_kernel(
             if (sc_base + lane < lim) {
 #pragma unroll
                 for (int i = 0; i < NQ; ++i)
-                    if (i < n_g) out[(int64_t)i * scores_stride + sc_base + lane] = sc[i];
+                    if (i < n_g) out[(int64_t)i * scores_stride + sc_base + lane] = nan_first(sc[i]);  // NaN ranks first
             }
         };
         auto reduce = [&](int64_t base, const Batch &bt) {
+            // (rows at or past n_rows are computed like any other: they land in lanes store_parked never stores)
             bool ok[R];
+            if constexpr (FILTER) {
 #pragma unroll
-            for (int r = 0; r < R; ++r) {
-                ok[r] = base + r * GROUPS + grp < n_rows;
-                if constexpr (FILTER) ok[r] = ok[r] && source_ok(lds_allow, bt.sid[r]);
+                for (int r = 0; r < R; ++r) ok[r] = source_ok(lds_allow, bt.sid[r]);
             }
             const int slot0 = (int)(base - sc_base);  // the lane that parks the batch's first row
-            // Straight-line over the NQ slots of the group: behind the group's last query the slots hold whatever the LDS
-            // holds (computed, never stored) -- a branch per query turned the loop into a jump table and cost 40 VGPRs.
-            // Query i+1's slices are read from LDS while query i is computed.
-            f32x4 q[2][CH];
+            // Straight-line over the NQ / 2 query pairs of the group: behind the group's last query the slots hold whatever
+            // the LDS holds (computed, never stored) -- a branch per query turned the loop into a jump table and cost 40
+            // VGPRs.  Pair i+1's slices are read from LDS while pair i is computed.
+            // Two queries per FMA: v_pk_fma_f32 with the row element broadcast to both halves (op_sel) and the pair's
+            // elements side by side -- each half is the scan's chain for its query, element by element in the same order.
+            f32x4 q[2][2 * CH];
 #pragma unroll
-            for (int c = 0; c < CH; ++c) q[0][c] = q_lds[c * G + sub];
+            for (int c = 0; c < CH; ++c) {
+                q[0][2 * c] = q_lds[c * G + sub];
+                q[0][2 * c + 1] = q_lds[row_f4 + c * G + sub];
+            }
 #pragma unroll
-            for (int i = 0; i < NQ; ++i) {
-                if (i + 1 < NQ) {
+            for (int i = 0; i < NQ / 2; ++i) {
+                if (i + 1 < NQ / 2) {
 #pragma unroll
-                    for (int c = 0; c < CH; ++c) q[(i + 1) & 1][c] = q_lds[(i + 1) * row_f4 + c * G + sub];
-                }
-#pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    float acc = 0.f;
-#pragma unroll
-                    for (int c = 0; c < CH; ++c) acc = dot4(bt.v[r][c], q[i & 1][c], acc);
-                    acc = nan_first(group_sum<G>(acc));
-                    const float val = ok[r] ? acc : neg_inf<float>();
-#pragma unroll
-                    for (int g = 0; g < GROUPS; ++g) {
-                        const float sg = read_lane(val, g * G + G - 1);
-                        sc[i] = lane == slot0 + r * GROUPS + g ? sg : sc[i];  // rows past lim: lanes nobody stores
+                    for (int c = 0; c < CH; ++c) {
+                        q[(i + 1) & 1][2 * c] = q_lds[2 * (i + 1) * row_f4 + c * G + sub];
+                        q[(i + 1) & 1][2 * c + 1] = q_lds[(2 * (i + 1) + 1) * row_f4 + c * G + sub];
                     }
                 }
-                __builtin_amdgcn_sched_barrier(0);  // (or the scheduler hoists every query's LDS reads: 300+ VGPRs)
+                // The FMA chains of the batch's R row-groups and the 2 * R reductions behind them are independent of each
+                // other: they are written out interleaved, instruction by instruction, so that a wave always has an
+                // instruction whose operands are ready (a chain on its own waits out the VALU latency at every step,
+                // and a DPP read needs two wait states behind the write: the dependent form was 25 % s_nop).
+                f32x2 acc2[R];
+#pragma unroll
+                for (int r = 0; r < R; ++r) acc2[r] = f32x2{0.f, 0.f};
+#pragma unroll
+                for (int c = 0; c < CH; ++c) {
+                    const f32x4 q01 = q[i & 1][2 * c], q23 = q[i & 1][2 * c + 1];
+                    if constexpr (R == 2) {
+                        const f32x4 a0 = bt.v[0][c], a1 = bt.v[1][c];
+                        asm("v_pk_fma_f32 %0, %2, %6, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]\n\t"
+                            "v_pk_fma_f32 %1, %4, %6, %1 op_sel:[0,0,0] op_sel_hi:[0,1,1]\n\t"
+                            "v_pk_fma_f32 %0, %2, %7, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
+                            "v_pk_fma_f32 %1, %4, %7, %1 op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
+                            "v_pk_fma_f32 %0, %3, %8, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]\n\t"
+                            "v_pk_fma_f32 %1, %5, %8, %1 op_sel:[0,0,0] op_sel_hi:[0,1,1]\n\t"
+                            "v_pk_fma_f32 %0, %3, %9, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
+                            "v_pk_fma_f32 %1, %5, %9, %1 op_sel:[1,0,0] op_sel_hi:[1,1,1]"
+                            : "+v"(acc2[0]), "+v"(acc2[1])
+                            : "v"(a0.xy), "v"(a0.zw), "v"(a1.xy), "v"(a1.zw), "v"(q01.xy), "v"(q01.zw), "v"(q23.xy),
+                              "v"(q23.zw));
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < R; ++r) {
+                            const f32x4 a = bt.v[r][c];
+                            asm("v_pk_fma_f32 %0, %1, %3, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]\n\t"
+                                "v_pk_fma_f32 %0, %1, %4, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
+                                "v_pk_fma_f32 %0, %2, %5, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]\n\t"
+                                "v_pk_fma_f32 %0, %2, %6, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]"
+                                : "+v"(acc2[r])
+                                : "v"(a.xy), "v"(a.zw), "v"(q01.xy), "v"(q01.zw), "v"(q23.xy), "v"(q23.zw));
+                        }
+                    }
+                }
+                asm volatile("s_nop 1" ::: "memory");  // the reduction's DPP reads: two wait states behind the last FMA
+                float red[2 * R];  // value 2 * r + h: row-group r, query 2 * i + h
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    red[2 * r] = acc2[r].x;
+                    red[2 * r + 1] = acc2[r].y;
+                }
+                tile_group_sums<G, 2 * R>(red);
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        float acc = red[2 * r + h];
+                        if constexpr (FILTER) acc = ok[r] ? acc : neg_inf<float>();
+                        // the leader lane's sum into lane `slot` of the parking register: readlane + writelane (scalar slot)
+#pragma unroll
+                        for (int g = 0; g < GROUPS; ++g) {
+                            const int sum_bits = __builtin_amdgcn_readlane(__float_as_int(acc), g * G + G - 1);
+                            // (lane select through m0: one SGPR operand per VALU instruction on gfx9)
+                            asm("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0"
+                                : "+v"(sc[2 * i + h])
+                                : "s"(sum_bits), "s"(slot0 + r * GROUPS + g)
+                                : "m0");
+                        }
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);  // (or the scheduler hoists every pair's LDS reads: 300+ VGPRs)
             }
             if (slot0 + RW == kWave) {
                 store_parked();
