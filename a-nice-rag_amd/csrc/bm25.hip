@@ -136,6 +136,13 @@ struct Bm25Queries {
     double *blk_score[kScanGroupMax];   // per-partition lists of the query's slot (selection form)
     uint32_t *blk_row[kScanGroupMax];
     double *scores[kScanGroupMax];      // n_docs scores (SCORES form)
+    // SCORES form for LISTS of queries (rank_batch.hip): any number of queries per launch, described in HBM instead of
+    // the kernel arguments -- query y's terms are terms_base[term_off[y] .. term_off[y + 1]), its scores go to
+    // scores_base + y * scores_stride; a query without terms writes nothing.  term_off == nullptr: the arrays above.
+    const int64_t *term_off;
+    const int32_t *terms_base;
+    double *scores_base;
+    int64_t scores_stride;
 };
 
 // DPT: documents per thread (THREADS * DPT = the largest partition the form takes).  Three forms:
@@ -154,11 +161,14 @@ __global__ __launch_bounds__(THREADS, THREADS == kBm25Threads ? 5 : (DPT == kDoc
     int32_t n_parts, int32_t part_docs, int64_t n_docs, int64_t n_vocab, Bm25Queries Q, int32_t k,
     const uint16_t *__restrict__ src, const uint32_t *__restrict__ allow_bits, int64_t sentinel) {
     const int qy = GROUPED ? (int)blockIdx.y : 0;
-    const int32_t *__restrict__ terms = Q.terms[qy];
-    const int32_t n_terms = Q.n_terms[qy];
-    double *__restrict__ blk_score = Q.blk_score[qy];
-    uint32_t *__restrict__ blk_row = Q.blk_row[qy];
-    double *__restrict__ scores_out = Q.scores[qy];
+    const bool table = SCORES && GROUPED && Q.term_off != nullptr;
+    const int qa = table ? 0 : qy;  // (the arrays hold kScanGroupMax entries; a table launch has more queries than that)
+    const int32_t *__restrict__ terms = table ? Q.terms_base + Q.term_off[qy] : Q.terms[qa];
+    const int32_t n_terms = table ? (int32_t)(Q.term_off[qy + 1] - Q.term_off[qy]) : Q.n_terms[qa];
+    double *__restrict__ blk_score = Q.blk_score[qa];
+    uint32_t *__restrict__ blk_row = Q.blk_row[qa];
+    double *__restrict__ scores_out = table ? Q.scores_base + (int64_t)qy * Q.scores_stride : Q.scores[qa];
+    if (table && n_terms == 0) return;  // (the whole workgroup: nothing has been synchronised yet)
     extern __shared__ __attribute__((aligned(16))) unsigned char bm25_lds[];
     double *slice = reinterpret_cast<double *>(bm25_lds);
     constexpr int WAVES = THREADS / kWave;
@@ -696,7 +706,7 @@ int launch_bm25_lists_group(anrag_index *idx, hipStream_t st, const int32_t *con
     if ((rc = ensure_dynamic_lds(idx->device, reinterpret_cast<const void *>(&bm25_kernel<F, S, T, D, G>),          \
                                  bm25_lds_bytes(T, D, F))))                                                         \
         return rc
-    Bm25Queries Q;
+    Bm25Queries Q{};
     for (int i = 0; i < kScanGroupMax; ++i) {
         const int j = i < n_queries ? i : 0;
         Q.terms[i] = d_terms[j];
@@ -746,6 +756,43 @@ int launch_bm25_lists_group(anrag_index *idx, hipStream_t st, const int32_t *con
 #undef ANRAG_BM25_ATTR
         ANRAG_HIP(hipGetLastError());
     }
+    return ANRAG_OK;
+}
+
+// Every score of n_queries queries in ONE launch (the full-ranking tiles of rank_batch.hip): query y's terms are
+// d_terms_base[d_term_off[y] .. d_term_off[y + 1]) (offsets in HBM, n_queries + 1 of them), its n_docs scores go to
+// d_scores_base + y * scores_stride.  A launch per 8 queries was 7 us of latency each on the evaluation corpus (3
+// partitions: 24 workgroups per launch on 256 CUs); one launch keeps every CU's three workgroup slots full.
+int launch_bm25_scores_table(anrag_index *idx, hipStream_t st, const int32_t *d_terms_base, const int64_t *d_term_off,
+                             int32_t n_queries, const uint32_t *d_allow_bits, double *d_scores_base, int64_t scores_stride) {
+    ANRAG_REQUIRE(n_queries >= 1 && n_queries <= 65535, "BM25 score table of %d queries", n_queries);
+    ANRAG_REQUIRE(scores_stride >= idx->n_docs, "score tile rows overlap");
+    const uint32_t *allow = idx->d_bm25_src ? d_allow_bits : nullptr;
+    Bm25Queries Q{};
+    Q.term_off = d_term_off;
+    Q.terms_base = d_terms_base;
+    Q.scores_base = d_scores_base;
+    Q.scores_stride = scores_stride;
+    const bool small = idx->part_docs <= kPostPerThread * kBm25ThreadsSmall;
+    const dim3 grid((unsigned)idx->n_parts, (unsigned)n_queries);
+    int rc;
+    LaunchTimer t(idx, ANRAG_KERNEL_BM25, st, n_queries);
+#define ANRAG_BM25_TABLE(F, T, D)                                                                                       \
+    do {                                                                                                                \
+        if ((rc = ensure_dynamic_lds(idx->device, reinterpret_cast<const void *>(&bm25_kernel<F, true, T, D, true>),    \
+                                     bm25_lds_bytes(T, D, F))))                                                         \
+            return rc;                                                                                                  \
+        bm25_kernel<F, true, T, D, true><<<grid, T, bm25_lds_bytes(T, D, F), st>>>(                                      \
+            idx->d_indptr, idx->d_post_doc, idx->d_post_impact, idx->d_idf, idx->d_part_slot, idx->d_part_ptr,          \
+            idx->n_parts, idx->part_docs, idx->n_docs, idx->n_terms, Q, 0, idx->d_bm25_src, allow, idx->n_postings);    \
+    } while (0)
+    if (small) {
+        if (allow) ANRAG_BM25_TABLE(true, kBm25ThreadsSmall, kPostPerThread); else ANRAG_BM25_TABLE(false, kBm25ThreadsSmall, kPostPerThread);
+    } else {
+        if (allow) ANRAG_BM25_TABLE(true, kBm25ThreadsSmall, kDocsPerThreadTall); else ANRAG_BM25_TABLE(false, kBm25ThreadsSmall, kDocsPerThreadTall);
+    }
+#undef ANRAG_BM25_TABLE
+    ANRAG_HIP(hipGetLastError());
     return ANRAG_OK;
 }
 

@@ -290,6 +290,9 @@ int launch_bm25_lists(anrag_index *idx, hipStream_t st, const int32_t *d_terms, 
 int launch_bm25_lists_group(anrag_index *idx, hipStream_t st, const int32_t *const *d_terms, const int32_t *n_terms,
                             int32_t n_queries, int32_t k, const uint32_t *d_allow_bits, double *const *d_scores_out,
                             const int *sets);
+// ... every score of any number of queries in one launch, the queries described in HBM (bm25.hip)
+int launch_bm25_scores_table(anrag_index *idx, hipStream_t stream, const int32_t *d_terms_base, const int64_t *d_term_off,
+                             int32_t n_queries, const uint32_t *d_allow_bits, double *d_scores_base, int64_t scores_stride);
 // Tail of a query, ONE launch (tail.hip): merge the dense block lists of set `set` and/or the BM25 partition
 // lists into per-modality top-k, then either write both lists (kTailCandidates: d_out[0..k) dense,
 // [k..2k) BM25; with one modality only its k records at d_out[0..k)) or fuse them (kTailFuse: WRRF + top_n).

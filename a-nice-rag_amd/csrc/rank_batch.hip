@@ -739,8 +739,8 @@ extern "C" int anrag_rank_batch(const anrag_rank_leg *legs, int32_t n_legs, int3
         const int64_t stride = (leg_rows[l] + 63) / 64 * 64;
         per_query += stride * (dense ? 4 : 8) + (int64_t)leg_k[l] * 4 + 256 + 4 + 4;
         if (!fuse) per_query += (int64_t)leg_k[l] * 8 + 256;
-        per_query += dense ? (int64_t)legs[l].idx->dim * 4 : 0;
-        fixed += 2048 * 4 + 256 + (legs[l].doc_of_row ? leg_rows[l] * 4 + 256 : 0);
+        per_query += dense ? (int64_t)legs[l].idx->dim * 4 : 8;  // BM25: the query's offset into the chunk's terms
+        fixed += 2048 * 4 + 256 + 8 + 256 + (legs[l].doc_of_row ? leg_rows[l] * 4 + 256 : 0);
     }
     if (fuse && !fuse_in_lds) per_query += id_space * 12 + 512 + (int64_t)fuse_n * 12 + 512 + 4;
     if (fuse) per_query += 4 + 256;
@@ -767,6 +767,7 @@ extern "C" int anrag_rank_batch(const anrag_rank_leg *legs, int32_t n_legs, int3
         float *q = nullptr;
         int32_t *terms = nullptr;
         int32_t *seg_k = nullptr;
+        int64_t *term_off = nullptr;
         void *scores = nullptr;
         int64_t stride = 0;
         uint32_t *rows = nullptr;
@@ -800,6 +801,7 @@ extern "C" int anrag_rank_batch(const anrag_rank_leg *legs, int32_t n_legs, int3
         } else {
             ld[l].terms = cv.take<int32_t>(std::max<int64_t>(max_terms_chunk, 1));
             ld[l].seg_k = cv.take<int32_t>(chunk);
+            ld[l].term_off = cv.take<int64_t>(chunk + 1);
             ld[l].scores = cv.take<double>(chunk * ld[l].stride);
         }
         ld[l].rows = cv.take<uint32_t>(chunk * leg_k[l]);
@@ -842,6 +844,7 @@ extern "C" int anrag_rank_batch(const anrag_rank_leg *legs, int32_t n_legs, int3
         ANRAG_HIP(hipStreamSynchronize(st));
     }
     std::vector<int32_t> h_segk;
+    std::vector<int64_t> h_off;
     for (int64_t q0 = 0; q0 < n_queries; q0 += chunk) {
         const int32_t c = (int32_t)std::min<int64_t>(chunk, n_queries - q0);
         if (expect_id) {
@@ -856,7 +859,7 @@ extern "C" int anrag_rank_batch(const anrag_rank_leg *legs, int32_t n_legs, int3
                                          hipMemcpyHostToDevice, st));
                 float *tile = static_cast<float *>(ld[l].scores);
                 const int tile_n = getenv("ANRAG_RANK_SCAN_TILES") ? 0 : dense_tile_group_max(ix);
-                for (int32_t g0 = 0; tile_n > 0 && g0 < c; g0 += kTileLaunchMax)  // K1T: the rows once per tile_n queries
+                for (int32_t g0 = 0; tile_n > 0 && g0 < c; g0 += kTileLaunchMax)  // K1T: the rows once per launch
                     if ((rc = launch_dense_tile(ix, st, ld[l].q + (int64_t)g0 * ix->dim, ix->dim,
                                                 std::min<int32_t>(kTileLaunchMax, c - g0), ld[l].allow,
                                                 tile + (int64_t)g0 * ld[l].stride, ld[l].stride)))
@@ -888,25 +891,16 @@ extern "C" int anrag_rank_batch(const anrag_rank_leg *legs, int32_t n_legs, int3
                     h_segk[q] = n_terms > 0 ? leg_k[l] : 0;  // no tokens: the leg is skipped (search_engine.py:216-217)
                 }
                 ANRAG_HIP(hipMemcpyAsync(ld[l].seg_k, h_segk.data(), (size_t)c * 4, hipMemcpyHostToDevice, st));
-                ANRAG_HIP(hipStreamSynchronize(st));  // h_segk is reused
-                {  // K3 in its score-writing form, up to 8 queries per launch
-                    const int32_t *bt[kScanGroupMax];
-                    int32_t bn[kScanGroupMax];
-                    double *bo[kScanGroupMax];
-                    int nb = 0;
-                    for (int32_t q = 0; q <= c; ++q) {
-                        const int32_t n_terms = q < c ? (int32_t)(g.term_offsets[q0 + q + 1] - g.term_offsets[q0 + q]) : 0;
-                        if (q < c && n_terms > 0) {
-                            bt[nb] = ld[l].terms + (g.term_offsets[q0 + q] - t0);
-                            bn[nb] = n_terms;
-                            bo[nb++] = tile + (int64_t)q * ld[l].stride;
-                        }
-                        if (nb == kScanGroupMax || (q == c && nb > 0)) {
-                            if ((rc = launch_bm25_lists_group(ix, st, bt, bn, nb, 0, ld[l].allow, bo, nullptr))) return rc;
-                            nb = 0;
-                        }
-                    }
-                }
+                h_off.resize((size_t)c + 1);
+                for (int32_t q = 0; q <= c; ++q) h_off[q] = g.term_offsets[q0 + q] - t0;
+                ANRAG_HIP(hipMemcpyAsync(ld[l].term_off, h_off.data(), ((size_t)c + 1) * 8, hipMemcpyHostToDevice, st));
+                ANRAG_HIP(hipStreamSynchronize(st));  // h_segk and h_off are reused
+                // K3 in its score-writing form, the chunk's queries in launches of up to 32,768 (a query without terms
+                // writes nothing: its segment is sorted to length 0)
+                for (int32_t g0 = 0; g0 < c; g0 += 32768)
+                    if ((rc = launch_bm25_scores_table(ix, st, ld[l].terms, ld[l].term_off + g0, std::min<int32_t>(32768, c - g0),
+                                                       ld[l].allow, tile + (int64_t)g0 * ld[l].stride, ld[l].stride)))
+                        return rc;
                 if ((rc = launch_seg_sort<double, false>(device, st, c, tile, ld[l].stride, nullptr, 0, (int32_t)leg_rows[l],
                                                          leg_k[l], ld[l].seg_k, ld[l].rows, ld[l].row_keys, leg_k[l],
                                                          ld[l].cnt)))
