@@ -430,6 +430,166 @@ __global__ __launch_bounds__(kRankThreads) void seg_topk_sort_kernel(
     if (tid == 0) out_count[seg] = k_eff;
 }
 
+// ------------------------------------------------------------------ segments that fit the LDS: stable LSD radix sort
+// The bitonic network above costs log^2: 66 LDS round trips for 9,609 entries (the evaluation corpus), 117 us per fp32
+// segment, 72 % of the full-ranking route's GPU time.  A leg's segment has a property the network does not use: its entries
+// arrive in tie-break order (entry i = row i, ties go to the lower row), so a STABLE sort by descending score alone is the
+// whole order -- an LSD radix sort over the key bits only, 8 bits a pass: 4 passes for fp32 scores, 8 for fp64.
+//   * wave w owns entries [w * S, (w + 1) * S), S a multiple of 64; lane l of row j holds entry w * S + 64 j + l in
+//     REGISTERS for the whole pass, so the scatter is in place (everybody has read before anybody writes);
+//   * rank inside the wave, in entry order: per row, the lanes with the same digit find each other with 8 ballots
+//     (peers = AND over the digit's bits of "lanes whose bit equals mine"), the lowest of them bumps the wave's counter
+//     cnt[digit][wave] by the group's size, everyone takes (counter before + peers below me);
+//   * one exclusive scan over cnt in (digit, wave) order turns the counters into the waves' start offsets per digit.
+// Keys are the complemented order bits (ascending = best first); a non-candidate (-inf: filtered row) is all ones and
+// sorts behind every score.  Same order as the network's by construction (total order on (score desc, row asc)).
+constexpr int kRadixBits = 8, kRadixBins = 1 << kRadixBits, kRadixWaves = kRankThreads / kWave;
+template <int W>
+constexpr int radix_cap() { return W == 2 ? 16384 : 12288; }  // fp64: 3 words an entry + the counters must fit 160 KB
+template <int W>
+constexpr int radix_lds_bytes() {
+    return (kRankCtrlWords + W * radix_cap<W>()) * 4 + kRadixBins * kRadixWaves * 2 + kRadixWaves * 4;
+}
+static_assert(radix_lds_bytes<2>() <= 160 * 1024 && radix_lds_bytes<3>() <= 160 * 1024, "one workgroup's LDS");
+
+template <typename KEY>
+__global__ __launch_bounds__(kRankThreads) void seg_radix_sort_kernel(
+    const KEY *__restrict__ keys, int64_t key_stride, int32_t n, int32_t k, const int32_t *__restrict__ seg_k,
+    uint32_t *__restrict__ out_tie, double *__restrict__ out_key, int64_t out_stride, int32_t *__restrict__ out_count) {
+    constexpr int W = sizeof(KEY) == 4 ? 2 : 3, KW = W - 1;  // KW key words + the row
+    constexpr int CAP = radix_cap<W>();
+    constexpr int RMAX = CAP / kRankThreads;  // rows of 64 entries per wave
+    constexpr int T = kRankThreads, NW = kRadixWaves;
+    extern __shared__ __attribute__((aligned(16))) uint32_t rank_lds[];
+    uint32_t *ctrl = rank_lds;
+    uint32_t *arr = rank_lds + kRankCtrlWords;  // word w of entry i at arr[w * CAP + i]; word 0 = row, 1.. = key
+    uint16_t *cnt = reinterpret_cast<uint16_t *>(arr + W * CAP);  // [digit * NW + wave]
+    uint32_t *wsum = reinterpret_cast<uint32_t *>(cnt + kRadixBins * NW);
+
+    const int tid = threadIdx.x, lane = tid & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);
+    const int64_t seg = blockIdx.x;
+    int32_t kq = k;
+    if (seg_k) kq = seg_k[seg] < k ? seg_k[seg] : k;
+    if (kq <= 0) {
+        if (tid == 0) out_count[seg] = 0;
+        return;
+    }
+    const KEY *__restrict__ kp = keys + seg * key_stride;
+    const int32_t S = ((n + NW - 1) / NW + kWave - 1) / kWave * kWave;  // entries per wave
+    const int32_t R = S / kWave;                                       // rows per wave, <= RMAX
+    const int32_t e0 = wave * S + lane;
+
+    uint32_t k0[RMAX], k1[W == 3 ? RMAX : 1], row[RMAX];  // (separate arrays: a [row][word] array went to scratch)
+    uint32_t n_cand = 0;
+    if (tid == 0) ctrl[0] = 0;
+#pragma unroll
+    for (int j = 0; j < RMAX; ++j) {
+        if (j < R) {
+            const int32_t e = e0 + j * kWave;
+            const KEY v = e < n ? kp[e] : neg_inf<KEY>();
+            const bool cand = v != neg_inf<KEY>();
+            n_cand += (uint32_t)__builtin_popcountll(__ballot(cand));
+            row[j] = (uint32_t)e;
+            if constexpr (W == 2) {
+                k0[j] = cand ? ~order_bits(v) : 0xFFFFFFFFu;
+            } else {
+                const uint64_t b = cand ? ~order_bits(v) : ~0ull;
+                k0[j] = (uint32_t)b;
+                k1[j] = (uint32_t)(b >> 32);
+            }
+        }
+    }
+    __syncthreads();
+    if (lane == 0 && n_cand) atomicAdd(&ctrl[0], n_cand);
+
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    for (int pass = 0; pass < KW * 4; ++pass) {
+        const int sh = (pass & 3) * kRadixBits;
+        const bool hi = pass >= 4;  // fp64: the upper key word
+        for (int i = tid; i < kRadixBins * NW / 2; i += T) reinterpret_cast<uint32_t *>(cnt)[i] = 0;
+        __syncthreads();
+        uint32_t rank[RMAX], dig[RMAX];
+#pragma unroll
+        for (int j = 0; j < RMAX; ++j) {
+            if (j < R) {
+                uint32_t word = k0[j];
+                if constexpr (W == 3) word = hi ? k1[j] : k0[j];
+                const uint32_t d = (word >> sh) & (kRadixBins - 1);
+                const bool valid = e0 + j * kWave < S * NW;  // (always: every lane of a row holds an entry, real or padding)
+                unsigned long long peers = __ballot(valid);
+#pragma unroll
+                for (int b = 0; b < kRadixBits; ++b) {
+                    const bool bit = (d >> b) & 1u;
+                    const unsigned long long bal = __ballot(bit);
+                    peers &= bit ? bal : ~bal;
+                }
+                const uint32_t below = (uint32_t)__builtin_popcountll(peers & lt_mask);
+                const uint32_t group = (uint32_t)__builtin_popcountll(peers);
+                uint16_t *c = &cnt[d * NW + wave];
+                const uint32_t before = *c;
+                if (below == 0) *c = (uint16_t)(before + group);  // the group's lowest lane
+                rank[j] = before + below;
+                dig[j] = d;
+            }
+        }
+        __syncthreads();
+        {  // exclusive scan of cnt in index order: 4 counters a thread
+            const uint2 v = reinterpret_cast<const uint2 *>(cnt)[tid];
+            const uint32_t c0 = v.x & 0xFFFFu, c1 = v.x >> 16, c2 = v.y & 0xFFFFu, c3 = v.y >> 16;
+            const uint32_t s4 = c0 + c1 + c2 + c3;
+            uint32_t x = s4;  // inclusive scan over the wave's lanes
+#pragma unroll
+            for (int off = 1; off < kWave; off <<= 1) {
+                const uint32_t y = __shfl_up(x, off, kWave);
+                if (lane >= off) x += y;
+            }
+            if (lane == kWave - 1) wsum[wave] = x;
+            __syncthreads();
+            uint32_t base = 0;
+#pragma unroll
+            for (int w2 = 0; w2 < NW; ++w2) base += w2 < wave ? wsum[w2] : 0u;
+            const uint32_t ex = base + x - s4;
+            uint2 o;
+            o.x = (ex & 0xFFFFu) | ((ex + c0) << 16);
+            o.y = ((ex + c0 + c1) & 0xFFFFu) | ((ex + c0 + c1 + c2) << 16);
+            reinterpret_cast<uint2 *>(cnt)[tid] = o;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < RMAX; ++j) {
+            if (j < R) {
+                const uint32_t dest = (uint32_t)cnt[dig[j] * NW + wave] + rank[j];
+                arr[dest] = row[j];
+                arr[CAP + dest] = k0[j];
+                if constexpr (W == 3) arr[2 * CAP + dest] = k1[j];
+            }
+        }
+        __syncthreads();
+        if (pass + 1 < KW * 4) {
+#pragma unroll
+            for (int j = 0; j < RMAX; ++j) {
+                if (j < R) {
+                    const int32_t e = e0 + j * kWave;
+                    row[j] = arr[e];
+                    k0[j] = arr[CAP + e];
+                    if constexpr (W == 3) k1[j] = arr[2 * CAP + e];
+                }
+            }
+        }
+    }
+    const int32_t cand_all = (int32_t)ctrl[0];
+    const int32_t k_eff = kq < cand_all ? kq : cand_all;
+    for (int32_t i = tid; i < k_eff; i += T) {
+        out_tie[seg * out_stride + i] = arr[i];
+        if (out_key) {
+            if constexpr (W == 2) out_key[seg * out_stride + i] = (double)unorder_bits(~arr[CAP + i]);
+            else out_key[seg * out_stride + i] = unorder_bits(~(((uint64_t)arr[2 * CAP + i] << 32) | arr[CAP + i]));
+        }
+    }
+    if (tid == 0) out_count[seg] = k_eff;
+}
+
 // ------------------------------------------------------------------ fusion over row lists
 __global__ void rank_fill_kernel(double *__restrict__ f, uint32_t *__restrict__ t, int64_t total) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -521,6 +681,82 @@ __global__ __launch_bounds__(256) void rank_emit_single_kernel(const uint32_t *_
     if (i == 0) out_cnt[q] = c;
 }
 
+// One leg, and only the rank of the expected document is wanted (src/retrieval_eval.py:75-82 with a single list): no
+// select, no sort -- the rank is one more than the number of rows that beat the expected row under the list's order (score
+// desc, row asc), and the list's length is the number of candidates cut to k.  One workgroup per query, two passes over
+// the score segment (the first finds the expected document's row when the leg maps rows to documents).
+template <typename KEY>
+__global__ __launch_bounds__(kRankThreads) void rank_count_kernel(const KEY *__restrict__ keys, int64_t key_stride, int32_t n,
+                                                                  int32_t k, const int32_t *__restrict__ seg_k,
+                                                                  const int32_t *__restrict__ doc_of_row, int32_t top_n,
+                                                                  const int64_t *__restrict__ expect,
+                                                                  int32_t *__restrict__ out_rank,
+                                                                  int32_t *__restrict__ out_cnt) {
+    constexpr int T = kRankThreads;
+    __shared__ uint32_t ctrl[4];  // [0] candidates  [1] rows that beat the expected one  [2] its row + 1
+    const int tid = threadIdx.x, lane = tid & (kWave - 1);
+    const int64_t q = blockIdx.x;
+    int32_t kq = k;
+    if (seg_k) kq = seg_k[q] < k ? seg_k[q] : k;
+    if (kq <= 0) {
+        if (tid == 0) {
+            out_cnt[q] = 0;
+            out_rank[q] = -1;
+        }
+        return;
+    }
+    const KEY *__restrict__ kp = keys + q * key_stride;
+    const int64_t e = expect[q];
+    if (tid < 4) ctrl[tid] = 0;
+    __syncthreads();
+    if (doc_of_row) {  // (a leg names a document once: at most one thread finds it)
+        for (int32_t i = tid; i < n; i += T)
+            if ((int64_t)doc_of_row[i] == e) ctrl[2] = (uint32_t)i + 1u;
+    } else if (tid == 0 && e >= 0 && e < n) {
+        ctrl[2] = (uint32_t)e + 1u;
+    }
+    __syncthreads();
+    const int32_t r = (int32_t)ctrl[2] - 1;
+    const KEY ke = r >= 0 ? kp[r] : neg_inf<KEY>();
+    const bool listed = r >= 0 && ke != neg_inf<KEY>();
+    const auto be = order_bits(ke);
+    uint32_t cand = 0, better = 0;
+    for (int32_t base = 0; base < n; base += T * kRankLoads) {
+        KEY kv[kRankLoads];
+#pragma unroll
+        for (int u = 0; u < kRankLoads; ++u) {
+            const int32_t i = base + u * T + tid;
+            kv[u] = i < n ? kp[i] : neg_inf<KEY>();
+        }
+#pragma unroll
+        for (int u = 0; u < kRankLoads; ++u) {
+            const int32_t i = base + u * T + tid;
+            const bool c = kv[u] != neg_inf<KEY>();
+            const auto b = order_bits(kv[u]);
+            cand += c ? 1u : 0u;
+            better += c && (b > be || (b == be && i < r)) ? 1u : 0u;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        cand += __shfl_xor(cand, off, kWave);
+        better += __shfl_xor(better, off, kWave);
+    }
+    if (lane == 0) {
+        if (cand) atomicAdd(&ctrl[0], cand);
+        if (better) atomicAdd(&ctrl[1], better);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const int32_t total = (int32_t)ctrl[0];
+        int32_t c = kq < total ? kq : total;
+        if (c > top_n) c = top_n;
+        const int32_t rank = (int32_t)ctrl[1] + 1;
+        out_cnt[q] = c;
+        out_rank[q] = listed && rank <= c ? rank : -1;
+    }
+}
+
 // Fusion of an id space that fits the LDS, ONE workgroup per query, one launch for everything behind the legs' lists:
 // the fp64 sums and the insertion keys live in LDS while the legs are added in order (a barrier between legs: a leg names
 // a document once, so its adds do not collide, and legs follow each other = the reference's dict update order), are
@@ -591,10 +827,36 @@ __global__ __launch_bounds__(kRankThreads) void rank_fuse_sort_kernel(const uint
     for (int off = 32; off >= 1; off >>= 1) named += __shfl_xor(named, off, kWave);
     if (lane == 0 && named) atomicAdd(&ctrl[0], (uint32_t)named);
     __syncthreads();
-    lds_bitonic_sort<W, CAP>(arr, id_space);
     const int32_t qe = (int32_t)blockIdx.x, out_ne = out_n;
     const int32_t n_named = (int32_t)ctrl[0];
     const int32_t k_out = n_named < out_ne ? n_named : out_ne;
+    if (out_id == nullptr) {
+        // Only the rank of the expected document is wanted (src/retrieval_eval.py:75-82 looks it up in the list): its
+        // rank is one more than the number of documents whose composite beats its own -- a count, no sort.
+        const int64_t e = expect[qe];
+        const bool known = e >= 0 && e < id_space && tie[e < id_space && e >= 0 ? e : 0] != 0u;
+        Comp<W> ce = comp_zero((Comp<W> *)nullptr);
+        if (known) comp_load<CAP>(arr, (int)e, ce);
+        uint32_t better = 0;
+        for (int32_t i = tid; i < id_space; i += T) {
+            Comp<W> c;
+            comp_load<CAP>(arr, i, c);
+            better += comp_gt(c, ce) ? 1u : 0u;
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) better += __shfl_xor(better, off, kWave);
+        if (tid == 0) ctrl[1] = 0;
+        __syncthreads();
+        if (lane == 0 && better) atomicAdd(&ctrl[1], better);
+        __syncthreads();
+        if (tid == 0) {
+            const int32_t r = (int32_t)ctrl[1] + 1;
+            out_rank[qe] = known && r <= k_out ? r : -1;
+            out_cnt[qe] = k_out;
+        }
+        return;
+    }
+    lds_bitonic_sort<W, CAP>(arr, id_space);
     for (int32_t i = tid; i < out_ne; i += T) {
         int64_t id = -1;
         double sc = -__builtin_huge_val();
@@ -618,8 +880,20 @@ static int launch_seg_sort(int device, hipStream_t st, int32_t n_seg, const KEY 
                            const uint32_t *ties, int64_t tie_stride, int32_t n, int32_t k, const int32_t *seg_k,
                            uint32_t *out_tie, double *out_key, int64_t out_stride, int32_t *out_count) {
     constexpr int W = sizeof(KEY) == 4 ? 2 : 3;
-    int rc = ensure_dynamic_lds(device, reinterpret_cast<const void *>(&seg_topk_sort_kernel<KEY, TIE>),
-                                rank_lds_bytes<W>());
+    int rc;
+    if constexpr (!TIE) {
+        static const bool bitonic = getenv("ANRAG_RANK_BITONIC") != nullptr;  // measurements: the network for every segment
+        if (n <= radix_cap<W>() && !bitonic) {  // the segment fits the LDS: stable radix sort, no select
+            if ((rc = ensure_dynamic_lds(device, reinterpret_cast<const void *>(&seg_radix_sort_kernel<KEY>),
+                                         radix_lds_bytes<W>())))
+                return rc;
+            seg_radix_sort_kernel<KEY><<<n_seg, kRankThreads, radix_lds_bytes<W>(), st>>>(keys, key_stride, n, k, seg_k, out_tie,
+                                                                                         out_key, out_stride, out_count);
+            ANRAG_HIP(hipGetLastError());
+            return ANRAG_OK;
+        }
+    }
+    rc = ensure_dynamic_lds(device, reinterpret_cast<const void *>(&seg_topk_sort_kernel<KEY, TIE>), rank_lds_bytes<W>());
     if (rc) return rc;
     seg_topk_sort_kernel<KEY, TIE><<<n_seg, kRankThreads, rank_lds_bytes<W>(), st>>>(
         keys, key_stride, ties, tie_stride, n, k, seg_k, out_tie, out_key, out_stride, out_count);
@@ -843,6 +1117,7 @@ extern "C" int anrag_rank_batch(const anrag_rank_leg *legs, int32_t n_legs, int3
         ANRAG_HIP(hipMemcpyAsync(d_fuse_legs, tab, sizeof(tab), hipMemcpyHostToDevice, st));
         ANRAG_HIP(hipStreamSynchronize(st));
     }
+    const bool count_only = !fuse && out_id == nullptr;  // (then out_rank is wanted: checked above)
     std::vector<int32_t> h_segk;
     std::vector<int64_t> h_off;
     for (int64_t q0 = 0; q0 < n_queries; q0 += chunk) {
@@ -876,8 +1151,11 @@ extern "C" int anrag_rank_batch(const anrag_rank_leg *legs, int32_t n_legs, int3
                                                       ld[l].stride)))
                         return rc;
                 }
-                if ((rc = launch_seg_sort<float, false>(device, st, c, tile, ld[l].stride, nullptr, 0, (int32_t)leg_rows[l],
-                                                        leg_k[l], nullptr, ld[l].rows, ld[l].row_keys, leg_k[l], ld[l].cnt)))
+                if (count_only)  // one list, rank of the expected document only: a count instead of the list
+                    rank_count_kernel<float><<<c, kRankThreads, 0, st>>>(tile, ld[l].stride, (int32_t)leg_rows[l], leg_k[l], nullptr,
+                                                                        ld[l].doc_of_row, out_n, d_expect, d_rank, d_out_cnt);
+                else if ((rc = launch_seg_sort<float, false>(device, st, c, tile, ld[l].stride, nullptr, 0, (int32_t)leg_rows[l],
+                                                             leg_k[l], nullptr, ld[l].rows, ld[l].row_keys, leg_k[l], ld[l].cnt)))
                     return rc;
             } else {
                 const int64_t t0 = g.term_offsets[q0];
@@ -901,18 +1179,22 @@ extern "C" int anrag_rank_batch(const anrag_rank_leg *legs, int32_t n_legs, int3
                     if ((rc = launch_bm25_scores_table(ix, st, ld[l].terms, ld[l].term_off + g0, std::min<int32_t>(32768, c - g0),
                                                        ld[l].allow, tile + (int64_t)g0 * ld[l].stride, ld[l].stride)))
                         return rc;
-                if ((rc = launch_seg_sort<double, false>(device, st, c, tile, ld[l].stride, nullptr, 0, (int32_t)leg_rows[l],
-                                                         leg_k[l], ld[l].seg_k, ld[l].rows, ld[l].row_keys, leg_k[l],
-                                                         ld[l].cnt)))
+                if (count_only)
+                    rank_count_kernel<double><<<c, kRankThreads, 0, st>>>(tile, ld[l].stride, (int32_t)leg_rows[l], leg_k[l],
+                                                                         ld[l].seg_k, ld[l].doc_of_row, out_n, d_expect, d_rank,
+                                                                         d_out_cnt);
+                else if ((rc = launch_seg_sort<double, false>(device, st, c, tile, ld[l].stride, nullptr, 0,
+                                                              (int32_t)leg_rows[l], leg_k[l], ld[l].seg_k, ld[l].rows,
+                                                              ld[l].row_keys, leg_k[l], ld[l].cnt)))
                     return rc;
             }
         }
         if (fuse && fuse_in_lds) {
             if ((rc = ensure_dynamic_lds(device, reinterpret_cast<const void *>(&rank_fuse_sort_kernel), rank_lds_bytes<3>())))
                 return rc;
-            rank_fuse_sort_kernel<<<c, kRankThreads, rank_lds_bytes<3>(), st>>>(d_fuse_legs, wrrf_k, (int32_t)id_space, out_n,
-                                                                                d_out_id, d_out_score, d_out_cnt, d_expect,
-                                                                                d_rank);
+            rank_fuse_sort_kernel<<<c, kRankThreads, rank_lds_bytes<3>(), st>>>(
+                d_fuse_legs, wrrf_k, (int32_t)id_space, out_n, out_id ? d_out_id : nullptr, d_out_score, d_out_cnt, d_expect,
+                d_rank);
         } else if (fuse) {
             const int64_t total = (int64_t)c * id_space;
             rank_fill_kernel<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(d_f, d_t, total);
@@ -934,7 +1216,7 @@ extern "C" int anrag_rank_batch(const anrag_rank_leg *legs, int32_t n_legs, int3
             const dim3 grid((unsigned)((out_n + 255) / 256), (unsigned)c);
             rank_emit_fused_kernel<<<grid, 256, 0, st>>>(L, d_stie, d_skey, fuse_n, d_scnt, out_n, d_out_id, d_out_score,
                                                          d_expect, d_rank);
-        } else {
+        } else if (!count_only) {
             const dim3 grid((unsigned)((out_n + 255) / 256), (unsigned)c);
             rank_emit_single_kernel<<<grid, 256, 0, st>>>(ld[0].rows, ld[0].row_keys, leg_k[0], ld[0].cnt,
                                                           ld[0].doc_of_row, out_n, d_out_id, d_out_score, d_out_cnt,

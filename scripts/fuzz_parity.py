@@ -310,6 +310,20 @@ def run_rank(budget: float = 60.0, seed: int = 0) -> int:
                 if min(top_n, space, len(legs) * k) > cap64:
                     top_n = cap64  # the fused order is cut to what one workgroup can sort (the call refuses beyond)
                 ids, sc, cnt = rank_batch(legs, nq, k, 40, top_n, id_space=space, want_scores=True)
+                # rank of an expected document, with the lists and without them (counts instead of sorts): a document
+                # of the answer, one past its cut, one nowhere -- for the fusion and for each leg alone
+                for use, kw in ((legs, dict(id_space=space)), (legs[:1], {}), (legs[-1:], {})):
+                    full, _, cfull = rank_batch(use, nq, k, 40, top_n, **kw)
+                    expect = np.array([full[i, rng.integers(0, cfull[i])] if cfull[i] and rng.random() < 0.7
+                                       else rng.integers(0, space + 3) for i in range(nq)], dtype=np.int64)
+                    _, _, c1, r1 = rank_batch(use, nq, k, 40, top_n, expect=expect, **kw)
+                    none, _, c2, r2 = rank_batch(use, nq, k, 40, top_n, expect=expect, want_ids=False, **kw)
+                    assert none is None and np.array_equal(cfull, c1) and np.array_equal(cfull, c2), ("rank counts", n, nb, k, top_n)
+                    for i in range(nq):
+                        pos = np.nonzero(full[i, :cfull[i]] == expect[i])[0]
+                        want = int(pos[0]) + 1 if len(pos) else -1
+                        assert r1[i] == want and r2[i] == want, ("rank of expected", n, nb, k, top_n, i, len(use), r1[i], r2[i], want)
+                        checks += 1
                 for i in range(nq):
                     lists = [(map_d[dl[i][0]].tolist(), "a")]
                     if three:
