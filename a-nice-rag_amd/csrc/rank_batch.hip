@@ -4,20 +4,22 @@
 //
 // Per chunk of C queries and per leg (a dense model or BM25; the reference's per-model blocks,
 // src/query_rag_retrieval.py:197-335):
-//   1. scores of every row into a tile [C][N]: K1 in its score-writing form, 8 queries per launch (the same
-//      arithmetic, bit for bit, as a single query's scan) / K3 in its score-writing form;
-//   2. seg_topk_sort_kernel, ONE workgroup per (query, leg): the reference's argsort()[::-1] / argpartition + argsort
+//   1. scores of every row into a tile [C][N]: K1T (dense_tile.hip: a batch of rows in registers, the launch's queries over
+//      it, bit for bit a single query's scan) / K3 in its score-writing form, the chunk's queries in one launch;
+//   2. ONE workgroup per (query, leg): the reference's argsort()[::-1] / argpartition + argsort
 //      (src/search_engine.py:83-87, :233-243) under the build's order (score desc, row asc), filtered rows (-inf)
-//      excluded.  Rows that fit the workgroup's LDS (<= 16,384 fp32 / 13,312 fp64 keys) are loaded and sorted by a
-//      bitonic network over (order-preserving key bits, ~row) composites; longer segments are first cut down by an MSD
-//      radix SELECT over the same composite (11-bit digits, LDS histogram, one pass over the segment per digit, stops
-//      as soon as "everything not below the current prefix" fits the LDS): histogram -> survivors -> sort only those.
-//   3. fusion (two or more legs), src/search_engine.py:21-34 on row lists instead of id strings: per leg in order, one
-//      launch adds w * (1 / (k + rank)) to F[query][doc] (a leg names a document once, so the additions of a document
-//      happen in leg order = the reference's dict update order; same fp64 bits) and stamps the document's
-//      first-insertion key (leg, position); then the SAME select + sort kernel orders F by (score desc, insertion key
-//      asc) = Python's stable sort, and an emit kernel maps the winners back to document ids.
-// Nothing here is GEMM-shaped: HBM-bound score tiles, LDS-bound sorts.
+//      excluded.  A segment that fits the LDS: seg_radix_sort_kernel, a stable LSD radix sort over the score bits (the
+//      entries arrive in row order).  Longer segments: seg_topk_sort_kernel -- an MSD radix SELECT over (order-preserving
+//      key bits, ~row) composites (11-bit digits, LDS histogram, one pass over the segment per digit, stops as soon as
+//      "everything not below the current prefix" fits the LDS), then a bitonic network over the survivors.
+//   3. fusion (two or more legs), src/search_engine.py:21-34 on row lists instead of id strings: w * (1 / (k + rank)) per
+//      leg in order (a leg names a document once, so the additions of a document happen in leg order = the reference's
+//      dict update order; same fp64 bits), ties to the first insertion (leg, position) = Python's stable sort.  An id
+//      space that fits the LDS: rank_fuse_sort_kernel, everything in one workgroup per query; larger ones: F arrays in
+//      HBM, an accumulate launch per leg, the select + sort kernel, an emit kernel.
+//   4. only the rank of an expected document wanted (expect_id, out_id == NULL: src/retrieval_eval.py:75-82): counts
+//      instead of sorts wherever a list is not needed (rank_count_kernel; the count in rank_fuse_sort_kernel).
+// HBM- / issue-bound score tiles, LDS-bound sorts.
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
