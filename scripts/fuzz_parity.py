@@ -233,7 +233,7 @@ def run_rank(budget: float = 60.0, seed: int = 0) -> int:
     rounds = checks = 0
     while time.time() < t_end:
         rounds += 1
-        n = int(rng.choice([3, 65, 1000, 4097, 9609, cap64 - 1, cap64, cap64 + 1, cap32, cap32 + 1, 20000, 40000]))
+        n = int(rng.choice([3, 65, 1000, 4097, 9609, 12287, 12288, 12289, cap64 - 1, cap64, cap64 + 1, cap32, cap32 + 1, 20000, 40000]))  # 12,288: the fp64 radix sort's capacity
         d = int(rng.choice([8, 64, 128, 384, 768]))
         nb = int(rng.choice([max(2, n // 2), n, n + 50]))
         n_src = int(rng.integers(1, 9))

@@ -215,6 +215,35 @@ def test_score_tiles_equal_the_scan_scores_at_every_kernel_shape(d):
                     assert np.array_equal(sc[i, :cnt[i]], full[want].astype(np.float64)), (d, n, i)
 
 
+@pytest.mark.parametrize("nb", [12287, 12288, 12289, 64, 1])
+def test_radix_sort_capacity_edges_bm25(nb):
+    """fp64 segments at the LDS radix sort's capacity (12,288 scores), one past it (the network takes over) and tiny ones;
+    heavy ties (most documents score 0: their order is the row order), k below / at / above the number of documents."""
+    from oracle import ref_search
+    from oracle.ref_bm25 import BM25Okapi
+    from anrag.bm25_index import Bm25Index
+    from anrag.index import Index, rank_batch
+
+    rng = np.random.default_rng(nb)
+    docs = [[f"w{int(j)}" for j in rng.integers(0, 400, size=int(rng.integers(1, 5)))] for _ in range(nb)]
+    bi = Bm25Index(docs, k1=1.7, b=0.83, epsilon=0.05)
+    ref = BM25Okapi(docs, k1=1.7, b=0.83, epsilon=0.05)
+    toks = [["w3", "w7", "w11"], ["absent"], ["w1"], [], ["w399", "w399", "w2"]]
+    tl = [bi.term_ids(t) for t in toks]
+    with Index(0) as bx:
+        bx.bm25_load(bi.indptr, bi.post_doc, bi.post_tf, bi.idf, bi.doc_len, bi.avgdl, bi.k1, bi.b)
+        for k in (nb, max(1, nb // 3), nb + 5):
+            ids, sc, cnt = rank_batch([dict(index=bx, weight=1.0, term_lists=tl)], len(toks), k, 40, k, want_scores=True)
+            for i, t in enumerate(toks):
+                if not t:
+                    assert cnt[i] == 0
+                    continue
+                scores = ref.get_scores(t)
+                want = ref_search.canonical_topk(scores, k)
+                assert cnt[i] == len(want) and ids[i, :cnt[i]].tolist() == want.tolist(), (nb, k, t)
+                assert np.array_equal(sc[i, :cnt[i]], scores[want])
+
+
 def test_select_path_heavy_ties_and_edges():
     """Segments longer than a workgroup's LDS (the radix select runs first): all-equal scores (every BM25 score 0: the
     k lowest rows win), duplicated rows, k = 1, a segment one element past the cap, a filter that keeps fewer than k."""
