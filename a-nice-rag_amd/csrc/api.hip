@@ -485,6 +485,7 @@ static int dense_single_enqueue(anrag_index *idx, const float *d_query, int32_t 
     return ANRAG_OK;
 }
 
+constexpr int kBm25Group = 16;  // queries per K3 launch of a BM25-only list (anrag_bm25_search_group_device)
 constexpr int kScanGroup = 8;  // queries per scan launch when a call brings several (measured, queries per launch
                                // 1 -> 4 -> 8: 53.6 -> 47.1 -> 45.7 us per query at 100k rows, 64.0 -> 57.9 us at 125k
                                // rows for 4, nothing at 1M rows)
@@ -713,9 +714,16 @@ int anrag_bm25_search_group_device(anrag_index *idx, const int32_t *const *d_ter
     for (int32_t i = 0; i < n_queries; ++i)
         ANRAG_REQUIRE(d_out[i] && n_terms[i] >= 0 && (n_terms[i] == 0 || d_term_ids[i]),
                       "query %d: needs an output block and term ids for its n_terms", i);
-    for (int32_t q0 = 0; q0 < n_queries; q0 += kScanGroup) {
-        const int n = n_queries - q0 < kScanGroup ? n_queries - q0 : kScanGroup;
-        GroupQuery g[kScanGroup];
+    // BM25 alone: kBm25Group queries per launch.  A launch of 8 is 1,960 workgroups on 768 slots at 1M documents: 2.6
+    // "rounds" of 18.7 us workgroups plus the ramp and the drain; 16 per launch halve the share of ramp and drain.
+    static const int group = [] {
+        const char *e = getenv("ANRAG_BM25_GROUP");  // measurements only
+        const int v = e ? atoi(e) : 0;
+        return v >= 1 && v <= kScanGroupMax ? v : kBm25Group;
+    }();
+    for (int32_t q0 = 0; q0 < n_queries; q0 += group) {
+        const int n = n_queries - q0 < group ? n_queries - q0 : group;
+        GroupQuery g[kScanGroupMax];
         for (int i = 0; i < n; ++i) g[i] = GroupQuery{nullptr, d_term_ids[q0 + i], n_terms[q0 + i], d_out[q0 + i], nullptr};
         int rc = hybrid_enqueue_group(idx, kTailCandidates, g, n, k, 0.0, 1.0, 0.0, 0, nullptr, d_allow_bits);
         if (rc) return rc;

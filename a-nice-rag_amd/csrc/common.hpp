@@ -19,7 +19,7 @@ constexpr int kWave = 64;            // CDNA wavefront
 constexpr int kListLen = 64;         // one top-k slot per lane (ANRAG_FUSED_K_MAX)
 constexpr int kScanThreads = 256;    // 4 waves: one scan workgroup per CU (sweep: profiles/r01_scan_config_sweep.txt)
 constexpr int kScanWaves = kScanThreads / kWave;
-constexpr int kScanGroupMax = 8;   // queries one scan launch can carry (dense_scan.hip)
+constexpr int kScanGroupMax = 16;  // queries one scan / K3 / tail launch can carry (dense_scan.hip, bm25.hip, tail.hip)
 constexpr int kPipeSlots = 32;     // queries in flight in the hybrid pipeline (list sets, events): four exchange
                                    // groups of 8, so a slow collective on the communication stream (which the tails
                                    // queue behind) does not stall the scans two groups later

@@ -989,8 +989,13 @@ extern "C" int anrag_rank_batch(const anrag_rank_leg *legs, int32_t n_legs, int3
         // order whatever the thread schedule (rank_accumulate_kernel)
         std::vector<uint64_t> seen((size_t)((id_space + 63) / 64));
         for (int l = 0; l < n_legs; ++l) {
-            std::fill(seen.begin(), seen.end(), 0ull);
             const int64_t *map = legs[l].doc_of_row;
+            if (!map) {  // row r is document r: injective as it stands
+                ANRAG_REQUIRE(leg_rows[l] <= id_space, "leg %d: %lld rows, documents [0, %lld)", l, (long long)leg_rows[l],
+                              (long long)id_space);
+                continue;
+            }
+            std::fill(seen.begin(), seen.end(), 0ull);
             for (int64_t r = 0; r < leg_rows[l]; ++r) {
                 const int64_t d = map ? map[r] : r;
                 ANRAG_REQUIRE(d >= 0 && d < id_space, "leg %d: row %lld maps to document %lld outside [0, %lld)", l,

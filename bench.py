@@ -699,32 +699,34 @@ def also_measurements(args, torch, nat, lib, idx, Index, synth, E, Q, T, n_terms
         PT = (C.c_void_p * qn)(*[T[i].data_ptr() for i in range(qn)])
         PO = (C.c_void_p * qn)(*[outk[i].data_ptr() for i in range(qn)])
         PN = (C.c_int32 * qn)(*[int(x) for x in n_terms])
-        gq = qn // 8 * 8
-        def run_groups(n):
-            for i in range(0, n, 8):
-                o = i % gq
-                nat.check(lib.anrag_bm25_search_group_device(
-                    idx.handle, C.cast(C.byref(PT, o * 8), C.c_void_p), C.cast(C.byref(PN, o * 4), C.c_void_p), 8, K, None,
-                    C.cast(C.byref(PO, o * 8), C.c_void_p)))
-            idx.sync()
-        if gq >= 8:
-            run_groups(gq)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            run_groups(8 * gq)
-            wall8 = time.perf_counter() - t0
-            idx.profile(True, kernels=[nat.KERNEL_BM25], every=1)
-            idx.profile_reset()
-            run_groups(2 * gq)
-            ms8, n8 = idx.profile_read(nat.KERNEL_BM25)
-            u8 = idx.profile_units(nat.KERNEL_BM25)
-            idx.profile(False)
-            us_q = ms8 / max(u8, 1) * 1e3
-            res["k3_bm25_8_per_launch"] = {
-                "kernel": "bm25_kernel (K3), 8 queries per launch (a workgroup set per query)", "bound": "hbm (latency-dominated)",
-                "algorithmic_bytes_per_query": byts, "avg_launch_us": ms8 / max(n8, 1) * 1e3, "launches": n8,
-                "us_per_query_in_kernel": us_q, "achieved": byts / (us_q * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": byts / (us_q * 1e-6) / 1e9 / HBM_PEAK_GBS, "queries_per_s_bm25_only": 8 * gq / wall8}
+        for per in (8, 16):  # 8: the hybrid pipeline's exchange group; 16: what a BM25-only list call launches
+            gq = qn // per * per
+            def run_groups(n):
+                for i in range(0, n, per):
+                    o = i % gq
+                    nat.check(lib.anrag_bm25_search_group_device(
+                        idx.handle, C.cast(C.byref(PT, o * 8), C.c_void_p), C.cast(C.byref(PN, o * 4), C.c_void_p), per, K, None,
+                        C.cast(C.byref(PO, o * 8), C.c_void_p)))
+                idx.sync()
+            if gq >= per:
+                run_groups(gq)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                run_groups(8 * gq)
+                wall8 = time.perf_counter() - t0
+                idx.profile(True, kernels=[nat.KERNEL_BM25], every=1)
+                idx.profile_reset()
+                run_groups(2 * gq)
+                ms8, n8 = idx.profile_read(nat.KERNEL_BM25)
+                u8 = idx.profile_units(nat.KERNEL_BM25)
+                idx.profile(False)
+                us_q = ms8 / max(u8, 1) * 1e3
+                res["k3_bm25_%d_per_launch" % per] = {
+                    "kernel": "bm25_kernel (K3), %d queries per launch (a workgroup set per query)" % per,
+                    "bound": "hbm (latency-dominated)",
+                    "algorithmic_bytes_per_query": byts, "avg_launch_us": ms8 / max(n8, 1) * 1e3, "launches": n8,
+                    "us_per_query_in_kernel": us_q, "achieved": byts / (us_q * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": byts / (us_q * 1e-6) / 1e9 / HBM_PEAK_GBS, "queries_per_s_bm25_only": 8 * gq / wall8}
     # ---- full-ranking mode for query lists (retrieval_eval.py's similarity_k = common_sections_n = 12000)
     try:
         res.update(full_ranking_measurements(args, torch, idx, Index, synth, E, Q, T, n_terms, post, device, local_rank))
@@ -765,7 +767,8 @@ def full_ranking_measurements(args, torch, idx, Index, synth, E, Q, T, n_terms, 
         t_single = (time.perf_counter() - t0) / sample
         same = all(np.array_equal(f, ids[i, :cnt[i]]) for i, f in enumerate(singles))
         touched = float(np.mean([sum(int(df[t]) for t in tl if t >= 0) for tl in term_lists]))
-        byts = (n_dense * dim * 4 + 2 * n_dense * 4) + (touched * 12 + 2 * n_docs * 8) + 2 * space * 12 + 2 * (kd + kb) * 4
+        tile_group = 16 if dim * 4 * 16 <= 48 * 1024 else max(2, (48 * 1024 // (dim * 4)) & ~1)  # queries K1T holds in LDS
+        byts = (n_dense * dim * 4 / tile_group + 2 * n_dense * 4) + (touched * 12 + 2 * n_docs * 8) + 2 * (kd + kb) * 4
         out[name] = {
             "what": "dense + BM25 full ranking and weighted RRF of %d queries in one anrag_rank_batch call, similarity_k = "
                     "common_sections_n = %d (retrieval_eval.py:142-143); host operands in, host results out" % (nq, KF),
@@ -774,10 +777,12 @@ def full_ranking_measurements(args, torch, idx, Index, synth, E, Q, T, n_terms, 
             "us_per_query_one_by_one": t_single * 1e6, "one_by_one_sample": sample,
             "speedup_vs_one_by_one": t_single / t_ids, "speedup_rank_only": t_single / t_rank,
             "ids_equal_one_by_one": bool(same), "rank_of_expected_ok": bool(np.all(ranks == 1)),
-            "algorithmic_bytes_per_query": byts, "bound": "hbm (score tiles) + lds (sorts)",
+            "algorithmic_bytes_per_query": byts,
+            "bound": "instruction issue (K1T score tiles: ~50 % of its VALU and of its HBM bound, DESIGN.md K4) + LDS (sorts)",
             "achieved": byts / t_rank / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": byts / t_rank / 1e9 / HBM_PEAK_GBS,
-            "bytes_are": "corpus read + score tile written and read (dense N*D*4 + 2*N*4; BM25 sum df*12 + 2*N*8) + fusion "
-                         "arrays filled and read (2*U*12) + ranked lists written and read"}
+            "bytes_are": "the rank-only mode's HBM bytes per query: corpus read once per %d queries (K1T) + score tile written "
+                         "and read (dense N*D*4/%d + 2*N*4; BM25 sum df*12 + 2*N*8) + the two ranked lists written and read; "
+                         "wall-clock includes the host side of the call" % (tile_group, tile_group)}
 
     # (1) the reference's corpus shape
     n1, d1 = 9609, 384
@@ -824,9 +829,10 @@ def full_ranking_measurements(args, torch, idx, Index, synth, E, Q, T, n_terms, 
     del E1, post1
     # (2) this run's corpus
     if post is not None and E.shape[0] >= 100_000:
-        nq = min(64, Q.shape[0])
-        qh = Q[:nq].cpu().numpy()
-        tl = [T[i, : n_terms[i]].cpu().numpy().astype(np.int32) for i in range(nq)]
+        nb = min(64, Q.shape[0])
+        nq = 256  # the run's queries four times over: a list long enough for two full score-tile launches (128 each)
+        qh = np.ascontiguousarray(np.tile(Q[:nb].cpu().numpy(), ((nq + nb - 1) // nb, 1))[:nq])
+        tl = [T[i % nb, : n_terms[i % nb]].cpu().numpy().astype(np.int32) for i in range(nq)]
         df = np.diff(post["indptr"])
         measure("full_ranking_%dx%d_k12000" % (E.shape[0], E.shape[1]), idx, idx, qh, tl, int(E.shape[0]), int(E.shape[1]),
                 int(len(post["doc_len"])), df, 4)

@@ -36,6 +36,8 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_k3 -o k3 -- pyth
 find $O/prof_k3 -name "*kernel_stats.csv" -exec cp {} $O/k3_kernel_stats_1_per_launch.csv \;
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_k3g -o k3 -- python3 $R/scripts/microbench_bm25.py 1000000 1024 8 > $O/k3_microbench_8.txt 2> $O/rocprof_k3g.err
 find $O/prof_k3g -name "*kernel_stats.csv" -exec cp {} $O/k3_kernel_stats_8_per_launch.csv \;
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_k3h -o k3 -- python3 $R/scripts/microbench_bm25.py 1000000 2048 16 > $O/k3_microbench_16.txt 2> $O/rocprof_k3h.err
+find $O/prof_k3h -name "*kernel_stats.csv" -exec cp {} $O/k3_kernel_stats_16_per_launch.csv \;
 # 3. full-ranking mode: the reference's corpus shape and the 1M corpus
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_rank1 -o rank -- python3 $R/scripts/microbench_rank.py 9609 384 12000 2048 8 > $O/rank_9609x384.txt 2> $O/rocprof_rank1.err
 find $O/prof_rank1 -name "*kernel_stats.csv" -exec cp {} $O/rank_9609x384_kernel_stats.csv \;
@@ -54,5 +56,5 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_rank -o 
 find $O/pmc_rank -name "*counter_collection.csv" -exec cp {} $O/pmc_FETCH_SIZE_rank_1Mx768.csv \;
 echo "pmc done"
 fi
-rm -rf $O/prof_bench $O/prof_k3 $O/prof_k3g $O/prof_rank1 $O/prof_rank2 $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/pmc_rank
+rm -rf $O/prof_bench $O/prof_k3 $O/prof_k3g $O/prof_k3h $O/prof_rank1 $O/prof_rank2 $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/pmc_rank
 ls -la $O

@@ -34,10 +34,11 @@ stats = {}
 for src, dst in (("bench_hybrid_1Mx768_kernel_stats", "r03_bench_hybrid_1Mx768_kernel_stats"),
                  ("k3_kernel_stats_1_per_launch", "r03_k3_kernel_stats_1_per_launch"),
                  ("k3_kernel_stats_8_per_launch", "r03_k3_kernel_stats_8_per_launch"),
+                 ("k3_kernel_stats_16_per_launch", "r03_k3_kernel_stats_16_per_launch"),
                  ("rank_9609x384_kernel_stats", "r03_rank_9609x384_kernel_stats"),
                  ("rank_1Mx768_kernel_stats", "r03_rank_1Mx768_kernel_stats")):
     stats[src] = trim_stats(os.path.join(SRC, src + ".csv"), os.path.join(DST, dst + ".csv"))
-for name in ("rank_9609x384", "rank_1Mx768", "k3_microbench_1", "k3_microbench_8"):
+for name in ("rank_9609x384", "rank_1Mx768", "k3_microbench_1", "k3_microbench_8", "k3_microbench_16"):
     line = open(os.path.join(SRC, name + ".txt")).read().strip().splitlines()[-1]
     open(os.path.join(DST, "r03_" + name + "_under_rocprofv3.txt"), "w").write(line + "\n")
 
