@@ -935,6 +935,75 @@ static int hybrid_enqueue_group(anrag_index *idx, TailMode tail, const GroupQuer
     return ANRAG_OK;
 }
 
+// One hybrid query per call on a SMALL corpus (the reference's own: 9,609 x 384): the pipeline above spends it on
+// plumbing -- three streams, two or three event records at 4-5 us of stream time each, waits between them: 44.8 us per
+// query for kernels of 4 + 8 + 9 us.  Here the query's scan, BM25 kernel and tail are launched back to back on ONE lane
+// stream (stream order is the only dependency; no events), and consecutive queries rotate over the lanes, whose streams
+// overlap on the device.  The lane's list sets and its back-pressure events are the single dense queries' (a dense
+// query's pending merge rides in this scan launch like in any other of the lane).  Large corpora keep the pipeline: there
+// K3 must run UNDER the scan, on its own stream.
+constexpr int64_t kHybridLanesMaxBytes = kScanLanesMaxBytes;  // 1 GiB (measured: 9,609 x 384 43.1 -> 17.3 us per query, 100k x 768
+                                                              // 56.9 -> 49.2, 250k x 768 119.6 -> 110.6; 1M x 768 keeps the pipeline)
+
+static bool hybrid_lane_route(const anrag_index *idx) {
+    static const int64_t max_bytes = [] {
+        const char *e = getenv("ANRAG_HYBRID_LANES_MAX_MB");  // measurements only (0 = the pipeline for every corpus)
+        return e ? (int64_t)atoll(e) << 20 : kHybridLanesMaxBytes;
+    }();
+    return idx->n_lanes >= 1 && idx->primary == idx->own_primary && idx->secondary == idx->own_secondary &&
+           idx->fusion == idx->own_fusion && idx->d_emb != nullptr && dense_scan_has_shape(idx) &&
+           (int64_t)idx->n_rows * idx->dim * 4 <= max_bytes;
+}
+
+static int hybrid_lane_enqueue(anrag_index *idx, TailMode tail, const GroupQuery &q, int32_t k, double w_dense,
+                               double w_bm25, double wrrf_k, int32_t top_n, const uint32_t *d_allow_dense,
+                               const uint32_t *d_allow_bm25) {
+    const bool use_dense = q.d_query != nullptr && (tail != kTailFuse || w_dense > 0.0);
+    bool use_bm25 = idx->d_post_doc != nullptr && (tail != kTailFuse || w_bm25 > 0.0) &&
+                    (q.n_terms > 0 || (!use_dense && tail != kTailFuse));
+    ANRAG_REQUIRE(use_dense || use_bm25, "hybrid search with neither a dense nor a BM25 leg");
+    int rc;
+    if (!idx->lanes_active) {
+        if ((rc = settle_pipeline(idx))) return rc;  // the pipeline's queries own the same list sets
+        idx->lanes_active = true;
+        idx->lane_rr = 0;
+        idx->lanes_in_use = (int64_t)idx->n_rows * idx->dim * 4 > kScanLanesMaxBytes ? 1 : idx->n_lanes;
+    }
+    const int L = idx->lanes_in_use;
+    const int l = (int)(idx->lane_rr++ % (uint64_t)L);
+    anrag_index::ScanLane &ln = idx->lane[l];
+    const int per_lane = kPipeSlots / L, every = per_lane / 4;
+    const uint64_t ls = ln.count;
+    const int set = l * per_lane + (int)(ls % (uint64_t)per_lane);
+    if (ls >= (uint64_t)per_lane) {  // the set's previous user: as in dense_single_enqueue (its event also covers a tail
+                                     // that ran right behind its own launches)
+        const int64_t m = ((int64_t)ls - per_lane + 2 + every - 1) / every - 1;
+        hipEvent_t ev = ln.ev[m % 4];
+        if (hipEventQuery(ev) != hipSuccess) ANRAG_HIP(hipEventSynchronize(ev));
+    }
+    if (use_dense) {
+        if ((rc = launch_dense_scan_group(idx, ln.st, &q.d_query, 1, k, d_allow_dense, nullptr, &set, 0,
+                                          ln.pending ? &ln.tail : nullptr)))
+            return rc;
+        ln.pending = false;
+    } else if (ln.pending) {  // no scan launch to carry a dense query's merge: launch it
+        ln.pending = false;
+        if ((rc = launch_tail(idx, ln.st, ln.tail.set, true, false, ln.tail.k, kTailCandidates, 0, 0, 0, 0, ln.tail.out, nullptr)))
+            return rc;
+    }
+    if (use_bm25 && (rc = launch_bm25_lists_group(idx, ln.st, &q.d_terms, &q.n_terms, 1, k, d_allow_bm25, nullptr, &set)))
+        return rc;
+    anrag_candidate *out = q.d_out;
+    int32_t *cnt = q.d_count;
+    if ((rc = launch_tail_group(idx, ln.st, &set, use_dense, &use_bm25, 1, k, tail, w_dense, w_bm25, wrrf_k, top_n, &out,
+                                cnt ? &cnt : nullptr)))
+        return rc;
+    ln.count = ls + 1;
+    if (ln.count % (uint64_t)every == 0) ANRAG_HIP(hipEventRecord(ln.ev[(ln.count / every - 1) % 4], ln.st));
+    idx->hyb_outstanding = true;
+    return ANRAG_OK;
+}
+
 static int hybrid_enqueue(anrag_index *idx, TailMode tail, const float *d_query, const int32_t *d_terms,
                           int32_t n_terms, int32_t k, double w_dense, double w_bm25, double wrrf_k, int32_t top_n,
                           const uint32_t *d_allow_dense, const uint32_t *d_allow_bm25, anrag_candidate *d_out,
@@ -988,6 +1057,9 @@ int anrag_hybrid_search_device(anrag_index *idx, const float *d_query, const int
     ANRAG_REQUIRE(similarity_k > 0 && similarity_k <= ANRAG_FUSED_K_MAX, "fused hybrid serves 1 <= similarity_k <= %d",
                   ANRAG_FUSED_K_MAX);
     ANRAG_REQUIRE(top_n > 0 && top_n <= 2 * ANRAG_FUSED_K_MAX, "top_n %d out of range", top_n);
+    if (hybrid_lane_route(idx) && d_query != nullptr && (!d_allow_dense_bits || idx->d_dense_src))
+        return hybrid_lane_enqueue(idx, kTailFuse, GroupQuery{d_query, d_term_ids, n_terms, d_out, d_count}, similarity_k,
+                                   w_dense, w_bm25, wrrf_k, top_n, d_allow_dense_bits, d_allow_bm25_bits);
     return hybrid_enqueue(idx, kTailFuse, d_query, d_term_ids, n_terms, similarity_k, w_dense, w_bm25, wrrf_k, top_n,
                           d_allow_dense_bits, d_allow_bm25_bits, d_out, d_count);
 }

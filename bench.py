@@ -826,6 +826,36 @@ def full_ranking_measurements(args, torch, idx, Index, synth, E, Q, T, n_terms, 
             "single_query_alone_p50_us": float(np.median(lat)) * 1e6,
             "single_query_alone_p99_us": float(np.percentile(lat, 99)) * 1e6,
             "timing": "wall-clock over 4096 back-to-back single-query calls; one query alone = call + anrag_index_sync"}
+        # ... and as HYBRID queries, one per call (what the reference's app asks of this corpus): scan, BM25 kernel and
+        # tail back to back on one of four lane streams
+        T1 = torch.full((64, 16), -1, dtype=torch.int32, device=device)
+        for i in range(64):
+            T1[i, : len(t1[i])] = torch.from_numpy(t1[i][:16]).to(device)
+        n1t = [min(16, len(t1[i])) for i in range(64)]
+        o2 = torch.zeros((64, 10, 2), dtype=torch.int64, device=device)
+        c2 = torch.zeros(64, dtype=torch.int32, device=device)
+        torch.cuda.synchronize()
+        def runh(m):
+            for i in range(m):
+                j = i % 64
+                nat.check(lib.anrag_hybrid_search_device(c1.handle, Q1[j].data_ptr(), T1[j].data_ptr(), n1t[j], 25, W_DENSE,
+                                                         W_BM25, WRRF_K, 10, None, None, o2[j].data_ptr(), c2[j:].data_ptr()))
+            c1.sync()
+        runh(256)
+        t0 = time.perf_counter()
+        runh(4096)
+        wh = (time.perf_counter() - t0) / 4096
+        lat = []
+        for i in range(200):
+            t0 = time.perf_counter()
+            runh(1)
+            lat.append(time.perf_counter() - t0)
+        out["c1_9609x384_hybrid_batch1"] = {
+            "kernel": "dense_scan_kernel + bm25_kernel + query_tail_kernel on one lane stream per query",
+            "bound": "launch / latency", "rows": n1, "dim": d1, "us_per_query": wh * 1e6, "queries_per_s": 1.0 / wh,
+            "single_query_alone_p50_us": float(np.median(lat)) * 1e6,
+            "single_query_alone_p99_us": float(np.percentile(lat, 99)) * 1e6,
+            "timing": "wall-clock over 4096 back-to-back hybrid calls (similarity_k 25, top 10), operands in HBM"}
     del E1, post1
     # (2) this run's corpus
     if post is not None and E.shape[0] >= 100_000:
