@@ -955,6 +955,23 @@ static bool hybrid_lane_route(const anrag_index *idx) {
            (int64_t)idx->n_rows * idx->dim * 4 <= max_bytes;
 }
 
+static int lanes_activate(anrag_index *idx) {
+    if (idx->lanes_active) return ANRAG_OK;
+    if (int rc = settle_pipeline(idx)) return rc;  // the pipeline's queries own the same list sets
+    idx->lanes_active = true;
+    idx->lane_rr = 0;
+    idx->lanes_in_use = (int64_t)idx->n_rows * idx->dim * 4 > kScanLanesMaxBytes ? 1 : idx->n_lanes;
+    return ANRAG_OK;
+}
+
+// the stream the NEXT lane query of this index will be launched on (the caller holds the index's lock): operands staged on
+// it are in place when the query's kernels start, results copied on it follow the tail
+static int hybrid_lane_peek(anrag_index *idx, hipStream_t *st) {
+    if (int rc = lanes_activate(idx)) return rc;
+    *st = idx->lane[idx->lane_rr % (uint64_t)idx->lanes_in_use].st;
+    return ANRAG_OK;
+}
+
 static int hybrid_lane_enqueue(anrag_index *idx, TailMode tail, const GroupQuery &q, int32_t k, double w_dense,
                                double w_bm25, double wrrf_k, int32_t top_n, const uint32_t *d_allow_dense,
                                const uint32_t *d_allow_bm25) {
@@ -963,12 +980,7 @@ static int hybrid_lane_enqueue(anrag_index *idx, TailMode tail, const GroupQuery
                     (q.n_terms > 0 || (!use_dense && tail != kTailFuse));
     ANRAG_REQUIRE(use_dense || use_bm25, "hybrid search with neither a dense nor a BM25 leg");
     int rc;
-    if (!idx->lanes_active) {
-        if ((rc = settle_pipeline(idx))) return rc;  // the pipeline's queries own the same list sets
-        idx->lanes_active = true;
-        idx->lane_rr = 0;
-        idx->lanes_in_use = (int64_t)idx->n_rows * idx->dim * 4 > kScanLanesMaxBytes ? 1 : idx->n_lanes;
-    }
+    if ((rc = lanes_activate(idx))) return rc;
     const int L = idx->lanes_in_use;
     const int l = (int)(idx->lane_rr++ % (uint64_t)L);
     anrag_index::ScanLane &ln = idx->lane[l];
@@ -1159,6 +1171,14 @@ struct HybridHostQuery {
     int enqueue(int s) {
         anrag_index::HostSlot &hs = idx->host_slot[s];
         hipStream_t P = idx->primary, S = idx->secondary;
+        // a corpus of at most 1 GiB: everything of the query -- operands up, three kernels, results down -- on one lane
+        // stream (hybrid_lane_enqueue); the host slot is still the ring's (the sequence number advances as in the pipeline)
+        const bool lanes = dense && hybrid_lane_route(idx);
+        if (lanes) {
+            int r0;
+            if ((r0 = hybrid_lane_peek(idx, &P))) return r0;
+            S = P;
+        }
         char *h_terms = hs.h + qbytes(), *h_aa = h_terms + kSlotTerms, *h_ab = h_aa + kSlotAllow, *h_out = h_ab + kSlotAllow;
         char *h_cnt = h_out + kSlotOut;
         const uint32_t *d_ad = nullptr, *d_ab = nullptr;
@@ -1175,10 +1195,16 @@ struct HybridHostQuery {
             memcpy(h_terms, term_ids, (size_t)n_terms * sizeof(int32_t));
             ANRAG_HIP(hipMemcpyAsync(hs.d_terms, h_terms, (size_t)n_terms * sizeof(int32_t), hipMemcpyHostToDevice, S));
         }
-        // takes pipeline slot hyb_seq % kPipeSlots == s and advances the sequence number
-        if ((r = hybrid_enqueue(idx, kTailFuse, hs.d_query, hs.d_terms, n_terms, similarity_k, w_dense, w_bm25, wrrf_k,
-                                top_n, d_ad, d_ab, hs.d_out, hs.d_count)))
+        if (lanes) {
+            if ((r = hybrid_lane_enqueue(idx, kTailFuse, GroupQuery{hs.d_query, hs.d_terms, n_terms, hs.d_out, hs.d_count},
+                                         similarity_k, w_dense, w_bm25, wrrf_k, top_n, d_ad, d_ab)))
+                return r;
+            idx->hyb_seq += 1;  // the ring's slot of the next caller
+        } else if ((r = hybrid_enqueue(idx, kTailFuse, hs.d_query, hs.d_terms, n_terms, similarity_k, w_dense, w_bm25, wrrf_k,
+                                       top_n, d_ad, d_ab, hs.d_out, hs.d_count))) {
+            // (takes pipeline slot hyb_seq % kPipeSlots == s and advances the sequence number)
             return r;
+        }
         // the fused tail runs on the secondary stream: the results follow it down
         ANRAG_HIP(hipMemcpyAsync(h_out, hs.d_out, (size_t)top_n * sizeof(anrag_candidate), hipMemcpyDeviceToHost, S));
         ANRAG_HIP(hipMemcpyAsync(h_cnt, hs.d_count, sizeof(int32_t), hipMemcpyDeviceToHost, S));
