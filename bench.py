@@ -744,23 +744,24 @@ def full_ranking_measurements(args, torch, idx, Index, synth, E, Q, T, n_terms, 
     out = {}
     KF = 12000
 
-    def measure(name, dense_idx, bm_idx, q_host, term_lists, n_dense, dim, n_docs, df, sample):
+    def measure(name, dense_idx, bm_idx, q_host, term_lists, n_dense, dim, n_docs, df, sample, KF=KF, top_n=None):
         nq = len(term_lists)
+        TN = KF if top_n is None else top_n
         legs = [dict(index=dense_idx, weight=W_DENSE, queries=q_host), dict(index=bm_idx, weight=W_BM25, term_lists=term_lists)]
         space = max(n_dense, n_docs)
-        rank_batch(legs, nq, KF, WRRF_K, KF, id_space=space)  # warm-up: scratch pool, LDS attributes
+        rank_batch(legs, nq, KF, WRRF_K, TN, id_space=space)  # warm-up: scratch pool, LDS attributes
         t0 = time.perf_counter()
-        ids, _, cnt = rank_batch(legs, nq, KF, WRRF_K, KF, id_space=space)
+        ids, _, cnt = rank_batch(legs, nq, KF, WRRF_K, TN, id_space=space)
         t_ids = (time.perf_counter() - t0) / nq
         expect = ids[:, 0].copy()
         t0 = time.perf_counter()
-        _, _, _, ranks = rank_batch(legs, nq, KF, WRRF_K, KF, id_space=space, expect=expect, want_ids=False)
+        _, _, _, ranks = rank_batch(legs, nq, KF, WRRF_K, TN, id_space=space, expect=expect, want_ids=False)
         t_rank = (time.perf_counter() - t0) / nq
         kd, kb = min(KF, n_dense), min(KF, n_docs)
         def one(i):  # the per-query path: score dump + library sort of all N, three more sorts for the fusion
             dd, _, dc = dense_idx.dense_search(q_host[i], kd)
             bd, _, bc = bm_idx.bm25_search(term_lists[i], kb)
-            return dense_idx.wrrf([dd[0, :int(dc[0])], bd[:bc]], [W_DENSE, W_BM25], WRRF_K, KF)[0]
+            return dense_idx.wrrf([dd[0, :int(dc[0])], bd[:bc]], [W_DENSE, W_BM25], WRRF_K, TN)[0]
         one(0)  # its scratch buffers are allocated on first use
         t0 = time.perf_counter()
         singles = [one(i) for i in range(sample)]
@@ -770,8 +771,9 @@ def full_ranking_measurements(args, torch, idx, Index, synth, E, Q, T, n_terms, 
         tile_group = 16 if dim * 4 * 16 <= 48 * 1024 else max(2, (48 * 1024 // (dim * 4)) & ~1)  # queries K1T holds in LDS
         byts = (n_dense * dim * 4 / tile_group + 2 * n_dense * 4) + (touched * 12 + 2 * n_docs * 8) + 2 * (kd + kb) * 4
         out[name] = {
-            "what": "dense + BM25 full ranking and weighted RRF of %d queries in one anrag_rank_batch call, similarity_k = "
-                    "common_sections_n = %d (retrieval_eval.py:142-143); host operands in, host results out" % (nq, KF),
+            "what": "dense + BM25 ranking and weighted RRF of %d queries in one anrag_rank_batch call, similarity_k = %d, "
+                    "common_sections_n = %d (retrieval_eval.py:142-143 at 12,000); host operands in, host results out"
+                    % (nq, KF, TN),
             "rows": n_dense, "dim": dim, "bm25_docs": n_docs, "queries": nq,
             "us_per_query_ids_out": t_ids * 1e6, "us_per_query_rank_of_expected_only": t_rank * 1e6,
             "us_per_query_one_by_one": t_single * 1e6, "one_by_one_sample": sample,
@@ -866,6 +868,10 @@ def full_ranking_measurements(args, torch, idx, Index, synth, E, Q, T, n_terms, 
         df = np.diff(post["indptr"])
         measure("full_ranking_%dx%d_k12000" % (E.shape[0], E.shape[1]), idx, idx, qh, tl, int(E.shape[0]), int(E.shape[1]),
                 int(len(post["doc_len"])), df, 4)
+        # the headline's query shape (similarity_k 25, top 10) asked as a LIST: score tiles read the corpus once per 16
+        # queries; "one by one" here is the per-query entry points, the device pipeline's list form is the headline's rate
+        measure("hybrid_list_%dx%d_k25" % (E.shape[0], E.shape[1]), idx, idx, qh, tl, int(E.shape[0]), int(E.shape[1]),
+                int(len(post["doc_len"])), df, 8, KF=25, top_n=10)
     return out
 
 

@@ -71,11 +71,13 @@ def test_retrieve_documents_matches_reference(world, fused):
         assert out == c["ids"], (fused, c["cfg"], c["tokens"])
 
 
-def test_retrieve_documents_batch_matches_reference(world):
+@pytest.mark.parametrize("ranked_from", [1, 10 ** 9])
+def test_retrieve_documents_batch_matches_reference(world, ranked_from):
     """The reference's own `retrieve_documents` outputs (72 cases: 1-2 dense models, with / without BM25 and filter,
-    k 10 ... 300) through the LIST entry point: cases that share their keyword arguments are asked together, so the
-    k <= 64 hybrid cases take `anrag_hybrid_search_batch` and everything else `anrag_rank_batch` (full-ranking mode);
-    and the expected-id rank the evaluation harness asks for equals the position in the reference's list."""
+    k 10 ... 300) through the LIST entry point: cases that share their keyword arguments are asked together.  The
+    k <= 64 hybrid cases take `anrag_hybrid_search_batch` (short lists: `ranked_from` = never) or, like everything else,
+    `anrag_rank_batch` (lists of 16 and more in production: `ranked_from` = 1 sends every list there); and the
+    expected-id rank the evaluation harness asks for equals the position in the reference's list."""
     import json
 
     from oracle.make_golden import synth_query
@@ -83,6 +85,7 @@ def test_retrieve_documents_batch_matches_reference(world):
 
     g, cfg, e1, e2, kept = world
     system = RetrievalEvaluationSystem(cfg)
+    system.RANKED_LIST_MIN = ranked_from
     groups = {}
     for c in g["cases"]:
         groups.setdefault(json.dumps(c["cfg"], sort_keys=True), []).append(c)
