@@ -305,6 +305,12 @@ int dense_tile_group_max(const anrag_index *idx) {
 // One launch; inside it the queries go through LDS in groups of dense_tile_group_max().
 int launch_dense_tile(anrag_index *idx, hipStream_t st, const float *d_queries, int64_t q_stride, int32_t n_queries,
                       const uint32_t *d_allow_bits, float *d_scores_out, int64_t scores_stride) {
+    {  // rows of 256 / 512 / 768 floats, corpora that fill the chip: the matrix-core form (dense_tile_mfma.hip), same bits
+        static const int mfma = [] { const char *e = getenv("ANRAG_TILE_MFMA"); return e ? atoi(e) : 1; }();  // 0: measurements
+        if (mfma && dense_tile_mfma_has_shape(idx) && idx->n_rows >= 32 * (int64_t)idx->n_cus &&
+            scores_stride >= (idx->n_rows + 31) / 32 * 32 && scores_stride % 4 == 0)
+            return launch_dense_tile_mfma(idx, st, d_queries, q_stride, n_queries, d_allow_bits, d_scores_out, scores_stride);
+    }
     const int group = dense_tile_group_max(idx);
     ANRAG_REQUIRE(group > 0, "no tile kernel for dimension %d", idx->dim);
     ANRAG_REQUIRE(n_queries >= 1 && n_queries <= kTileLaunchMax, "tile launch of %d queries (at most %d)", n_queries,

@@ -215,6 +215,40 @@ def test_score_tiles_equal_the_scan_scores_at_every_kernel_shape(d):
                     assert np.array_equal(sc[i, :cnt[i]], full[want].astype(np.float64)), (d, n, i)
 
 
+@pytest.mark.parametrize("d", [512, 768, 256])
+def test_matrix_core_score_tiles_equal_the_scan_scores(d):
+    """K1T's matrix-core form (dense_tile_mfma.hip: one v_mfma_f32_16x16x4_f32 accumulation per lane slice = the scan's
+    per-lane FMA chain, then the scan's lane tree as vector adds) takes corpora of at least 32 rows per CU at 512 / 768
+    dimensions (256-d rows are scanned in another shape and stay on the VALU form: checked here too): every score bit for bit K1's (`dense_scores`, one query at a time) -- a row count that is no multiple
+    of the 32-row blocks, 37 queries (launch groups of 32 and tiles of 16 end inside the list), equal rows, a NaN row
+    (ranks first), a source filter; and the VALU form (ANRAG_TILE_MFMA=0 is read once per process: here through the
+    small-corpus route, which always takes it) agrees by the other test."""
+    from oracle import ref_search
+    from anrag.index import Index, rank_batch
+
+    rng = np.random.default_rng(1000 + d)
+    n, nq = 8192 + 37, 37
+    e = rng.standard_normal((n, d), dtype=np.float32)
+    e *= np.exp(rng.uniform(-6, 6, size=(n, 1))).astype(np.float32)  # magnitudes over five decades
+    e[n // 2] = e[1]
+    e[n - 1] = e[2]
+    e[77] = np.nan
+    q = rng.standard_normal((nq, d), dtype=np.float32)
+    q[5] *= np.float32(1e-12)
+    sid = (np.arange(n) % 5).astype(np.uint16)
+    allow = np.array([1, 0, 1, 1, 0], np.uint8)
+    with Index(0) as di:
+        di.dense_load(e, source_id=sid)
+        for al in (None, allow):
+            ids, sc, cnt = rank_batch([dict(index=di, weight=1.0, allow=al, queries=q)], nq, n, 40, n, want_scores=True)
+            ok = None if al is None else al.astype(bool)[sid]
+            for i in range(nq):
+                full = di.dense_scores(q[i])
+                want = ref_search.canonical_topk(full, n, ok)
+                assert cnt[i] == len(want) and ids[i, :cnt[i]].tolist() == want.tolist(), (d, i)
+                assert np.array_equal(sc[i, :cnt[i]], full[want].astype(np.float64)), (d, i)
+
+
 @pytest.mark.parametrize("nb", [12287, 12288, 12289, 64, 1])
 def test_radix_sort_capacity_edges_bm25(nb):
     """fp64 segments at the LDS radix sort's capacity (12,288 scores), one past it (the network takes over) and tiny ones;
