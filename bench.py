@@ -769,6 +769,8 @@ def full_ranking_measurements(args, torch, idx, Index, synth, E, Q, T, n_terms, 
         same = all(np.array_equal(f, ids[i, :cnt[i]]) for i, f in enumerate(singles))
         touched = float(np.mean([sum(int(df[t]) for t in tl if t >= 0) for tl in term_lists]))
         tile_group = 16 if dim * 4 * 16 <= 48 * 1024 else max(2, (48 * 1024 // (dim * 4)) & ~1)  # queries K1T holds in LDS
+        if dim in (512, 768) and n_dense >= 32 * 256:
+            tile_group = 32  # the matrix-core form (dense_tile_mfma.hip)
         byts = (n_dense * dim * 4 / tile_group + 2 * n_dense * 4) + (touched * 12 + 2 * n_docs * 8) + 2 * (kd + kb) * 4
         out[name] = {
             "what": "dense + BM25 ranking and weighted RRF of %d queries in one anrag_rank_batch call, similarity_k = %d, "
@@ -780,7 +782,7 @@ def full_ranking_measurements(args, torch, idx, Index, synth, E, Q, T, n_terms, 
             "speedup_vs_one_by_one": t_single / t_ids, "speedup_rank_only": t_single / t_rank,
             "ids_equal_one_by_one": bool(same), "rank_of_expected_ok": bool(np.all(ranks == 1)),
             "algorithmic_bytes_per_query": byts,
-            "bound": "instruction issue (K1T score tiles: ~50 % of its VALU and of its HBM bound, DESIGN.md K4) + LDS (sorts)",
+            "bound": "K1T score tiles (matrix cores at 512 / 768-d on large corpora, else VALU: DESIGN.md K4) + LDS (sorts)",
             "achieved": byts / t_rank / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": byts / t_rank / 1e9 / HBM_PEAK_GBS,
             "bytes_are": "the rank-only mode's HBM bytes per query: corpus read once per %d queries (K1T) + score tile written "
                          "and read (dense N*D*4/%d + 2*N*4; BM25 sum df*12 + 2*N*8) + the two ranked lists written and read; "

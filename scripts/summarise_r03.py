@@ -92,7 +92,7 @@ json.dump(sel, open(os.path.join(DST, "r03_pmc_rank_select.json"), "w"), indent=
 
 # K1T (dense_tile.hip) on the 1M x 768 corpus: time per launch from the kernel trace, HBM bytes per launch from the FETCH_SIZE
 # pass of the same command (x2: 16 B / lane streaming reads, as for K1)
-tile_name = "dense_tile_kernel<64, 3, 2, false>"
+tile_name = "dense_tile_mfma_kernel<3, false>"
 tile = {"kernel": tile_name, "rows": 1000000, "dim": 768, "commit": commit}
 for k, v in stats["rank_1Mx768_kernel_stats"].items():
     if k.startswith("anrag::" + tile_name) or tile_name in k:
@@ -101,7 +101,7 @@ tf = pmc(os.path.join(SRC, "pmc_FETCH_SIZE_rank_1Mx768.csv"), tile_name, "FETCH_
 if tf and "avg_launch_ns" in tile:
     q_per_launch = 128
     tile["queries_per_launch"] = q_per_launch
-    tile["queries_in_lds_at_a_time"] = 16
+    tile["queries_in_lds_at_a_time"] = 32
     tile["FETCH_SIZE_KB_raw_per_launch"] = statistics.median(tf)
     tile["hbm_bytes_per_launch"] = statistics.median(tf) * 2 * 1024
     tile["one_pass_over_the_corpus_bytes"] = 3072000000
@@ -110,7 +110,8 @@ if tf and "avg_launch_ns" in tile:
     tile["hbm_frac_of_8TBps"] = tile["hbm_GBps"] / 8000.0
     tile["flop_per_launch"] = 2.0 * 1000000 * 768 * q_per_launch
     tile["TFLOPs"] = tile["flop_per_launch"] / tile["avg_launch_ns"] / 1e3
-    tile["frac_of_157.3_TF_fp32_vector_peak"] = tile["TFLOPs"] / 157.3
+    tile["frac_of_157.3_TF_fp32_matrix_peak"] = tile["TFLOPs"] / 157.3
+    tile["mfma_pipe_cycles_per_launch_per_simd"] = (1000000 / 16) * (q_per_launch / 16) * 192 * 32 / 1024
     tile["us_per_query"] = tile["avg_launch_ns"] / 1e3 / q_per_launch
 json.dump(tile, open(os.path.join(DST, "r03_k1t_tile.json"), "w"), indent=1)
 
