@@ -15,7 +15,7 @@
 // Workgroup: 8 waves = 2 row tiles x 2 query tiles x 2 halves of the 64 slices (two waves per SIMD: one's tree and waits
 // hide under the other's MFMAs; the halves meet through LDS, lower + upper) over a block of 32 rows; the launch's 32 queries stay in LDS for the
 // whole kernel (padded rows: a 16 x 4 operand read touches every bank exactly twice), the rows go through LDS one
-// 256-column chunk at a time, fetched a chunk ahead into registers.
+// 256-column chunk at a time, fetched a whole block ahead into registers.
 #include "common.hpp"
 #include "wave_topk.hpp"
 #include "dense_scan_common.hpp"
@@ -63,19 +63,16 @@ __global__ __launch_bounds__(kMfmaThreads) void dense_tile_mfma_kernel(
         for (int i = tid; i < 2048; i += T) lds_allow[i] = allow_bits[i];
 
     const int64_t n_blocks = (n_rows + kMfmaTileRows - 1) / kMfmaTileRows;
-    // The workgroup's work is a sequence of STEPS (block, chunk); a step's rows are 32 x 64 float4 = 4 float4 per thread,
-    // row-major (1 KB runs: coalesced), fetched TWO steps ahead into registers (one step of MFMAs is ~1 us: less than an
-    // HBM round trip under load).
+    // A block's rows come in CH chunks of 32 x 64 float4 = 4 float4 per thread and chunk, row-major (1 KB runs: coalesced);
+    // chunk c of the NEXT block is fetched into register set c right after chunk c of this block has gone to LDS: a whole
+    // block (CH steps of MFMAs, ~2 us) ahead of its use -- more than an HBM round trip under load.  The fetches are
+    // UNCONDITIONAL (behind the last block: the last block again) and the register sets are static: a load behind a branch
+    // makes the compiler wait for every outstanding load at the next use, i.e. for the chunk just issued -- one exposed HBM
+    // round trip per step, the pipe a quarter busy.
     const int64_t my_blocks = blockIdx.x < n_blocks ? (n_blocks - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
-    const int64_t n_steps = my_blocks * CH;
-    // (fetches are UNCONDITIONAL -- behind the last step the last one again -- and the two register sets alternate
-    // statically: a load behind a branch makes the compiler wait for every outstanding load at the next use, i.e. for the
-    // step just issued: one exposed HBM round trip per step, the pipe a quarter busy)
-    f32x4 stage0[4], stage1[4];
-    auto fetch = [&](int64_t step, f32x4 (&st)[4]) {
-        step = step < n_steps ? step : n_steps - 1;
-        const int64_t blk = blockIdx.x + (step / CH) * gridDim.x;
-        const int c = (int)(step % CH);
+    if (my_blocks == 0) return;  // (the whole workgroup)
+    f32x4 stage[CH][4];
+    auto fetch = [&](int64_t blk, int c, f32x4 (&st)[4]) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int g = tid + T * u, r = g / CHUNK_F4, f = g % CHUNK_F4;
@@ -95,79 +92,79 @@ __global__ __launch_bounds__(kMfmaThreads) void dense_tile_mfma_kernel(
             d[3 * G] = st[u].w;
         }
     };
-    if (n_steps == 0) return;  // (the whole workgroup: blockIdx.x >= n_blocks)
-    fetch(0, stage0);
-    __builtin_amdgcn_sched_barrier(0);  // in THIS order: the loop's counted waits (vmcnt) assume set 0's loads are the older
-    fetch(1, stage1);
-    __builtin_amdgcn_sched_barrier(0);
+    int order = 0;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        // The loop's counted waits (s_waitcnt vmcnt) assume set 0's loads are the oldest outstanding ones.  The first
+        // block's fetches are therefore completed one set after the other (left alone the compiler interleaved them,
+        // and every first put of a block then waited for the chunks issued a step before): three round trips, once.
+        fetch(blockIdx.x + order, c, stage[c]);
+        // (the next set's addresses depend on a 0 produced BEHIND this wait: nothing else keeps loads of read-only,
+        // unaliased memory from moving across it)
+        if (c + 1 < CH) asm volatile("s_waitcnt vmcnt(0)\n\tv_mov_b32 %0, 0" : "=v"(order) : : "memory");
+    }
     const int li = lane & 15, lk = lane >> 4;  // operand lane layout: A[i = li][k = lk], B[k = lk][j = li]
     constexpr int HS = G / 2, NG = HS / 4;      // slices and groups of four per half
     const f32x4 *a_base = reinterpret_cast<const f32x4 *>(As + (rt * 16 + li) * ASTR + lk * G) + half * NG;
     const f32x4 *b_base = reinterpret_cast<const f32x4 *>(Qs + (qt * 16 + li) * QSTR + lk * G) + half * NG;
-    f32x4 acc[HS];
-    auto do_step = [&](int64_t step, f32x4 (&st)[4]) {
-        const int c = (int)(step % CH);
-        const int64_t blk = blockIdx.x + (step / CH) * gridDim.x;
-        if (c == 0) {
+    for (int64_t bi = 0; bi < my_blocks; ++bi) {
+        const int64_t blk = blockIdx.x + bi * gridDim.x;
+        const int64_t nxt = blockIdx.x + (bi + 1 < my_blocks ? bi + 1 : bi) * gridDim.x;
+        f32x4 acc[HS];
 #pragma unroll
-            for (int s = 0; s < HS; ++s) acc[s] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-        __syncthreads();  // the previous step's operand reads are done (first step: the queries are in place)
-        put(st);
-        fetch(step + 2, st);
-        __syncthreads();
-        // operands of four slices per 16-byte read, fetched two groups (8 MFMAs) ahead of their use; the barriers pin that
-        // order (left alone the compiler read each pair right in front of its two MFMAs: one exposed LDS round trip per
-        // 64 cycles of work)
-        const f32x4 *bq = b_base + c * G;
-        f32x4 ab[3], bb[3];
-        ab[0] = a_base[0];
-        bb[0] = bq[0];
-        ab[1] = a_base[1];
-        bb[1] = bq[1];
-#pragma unroll
-        for (int g = 0; g < NG; ++g) {
-            if (g + 2 < NG) {
-                ab[(g + 2) % 3] = a_base[g + 2];
-                bb[(g + 2) % 3] = bq[g + 2];
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-                acc[4 * g + t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ab[g % 3][t], bb[g % 3][t], acc[4 * g + t], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        if (c == CH - 1 && step < n_steps) {  // (uniform: the workgroup's barrier below is met by every wave)
-            // the scan's lane tree over this half's 32 slices (neighbours first), then lower half + upper half
-#pragma unroll
-            for (int w = 1; w < HS; w <<= 1)
-#pragma unroll
-                for (int s = 0; s < HS; s += 2 * w) acc[s] = acc[s] + acc[s + w];
-            f32x4 out = acc[0];
-            if (half == 1) Xs[(rt * 2 + qt) * 64 + lane] = out;
+        for (int c = 0; c < CH; ++c) {
+            __syncthreads();  // the previous chunk's operand reads are done (first pass: the queries are in place)
+            put(stage[c]);
+            __builtin_amdgcn_sched_barrier(0);  // (the new loads behind the waits of the old ones)
+            fetch(nxt, c, stage[c]);
             __syncthreads();
-            if (half == 0) {
-                out = out + Xs[(rt * 2 + qt) * 64 + lane];
-                // lane holds rows (lane / 16) * 4 + 0..3 of the tile for query lane % 16: four consecutive rows of its score row
-                const int q = q0 + qt * 16 + li;
-                const int64_t row = blk * kMfmaTileRows + rt * 16 + lk * 4;
+            // operands of four slices per 16-byte read, fetched two groups (8 MFMAs) ahead of their use; the barriers pin
+            // that order (left alone the compiler read each pair right in front of its two MFMAs: one exposed LDS round
+            // trip per 64 cycles of work).  The first chunk's MFMAs take the literal 0 as C: no accumulators to clear.
+            const f32x4 *bq = b_base + c * G;
+            f32x4 ab[3], bb[3];
+            ab[0] = a_base[0];
+            bb[0] = bq[0];
+            ab[1] = a_base[1];
+            bb[1] = bq[1];
 #pragma unroll
-                for (int v = 0; v < 4; ++v) {
-                    float x = nan_first(out[v]);  // NaN ranks first (carried as +inf)
-                    if constexpr (FILTER) {
-                        const int64_t r = row + v < n_rows ? row + v : n_rows - 1;
-                        x = source_ok(lds_allow, src[r]) ? x : neg_inf<float>();
-                    }
-                    out[v] = x;
+            for (int g = 0; g < NG; ++g) {
+                if (g + 2 < NG) {
+                    ab[(g + 2) % 3] = a_base[g + 2];
+                    bb[(g + 2) % 3] = bq[g + 2];
                 }
-                if (q < n_q) *reinterpret_cast<f32x4 *>(&scores_out[(int64_t)q * scores_stride + row]) = out;
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    acc[4 * g + t] = __builtin_amdgcn_mfma_f32_16x16x4f32(
+                        ab[g % 3][t], bb[g % 3][t], c == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[4 * g + t], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
-    };
-    // steps in pairs (an odd count: one step more, computed into accumulators nobody reads)
-    for (int64_t step = 0; step < n_steps; step += 2) {
-        do_step(step, stage0);
-        do_step(step + 1, stage1);
+        // the scan's lane tree over this half's 32 slices (neighbours first), then lower half + upper half
+#pragma unroll
+        for (int w = 1; w < HS; w <<= 1)
+#pragma unroll
+            for (int s = 0; s < HS; s += 2 * w) acc[s] = acc[s] + acc[s + w];
+        f32x4 out = acc[0];
+        if (half == 1) Xs[(rt * 2 + qt) * 64 + lane] = out;
+        __syncthreads();
+        if (half == 0) {
+            out = out + Xs[(rt * 2 + qt) * 64 + lane];
+            // lane holds rows (lane / 16) * 4 + 0..3 of the tile for query lane % 16: four consecutive rows of its score row
+            const int q = q0 + qt * 16 + li;
+            const int64_t row = blk * kMfmaTileRows + rt * 16 + lk * 4;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                float x = nan_first(out[v]);  // NaN ranks first (carried as +inf)
+                if constexpr (FILTER) {
+                    const int64_t r = row + v < n_rows ? row + v : n_rows - 1;
+                    x = source_ok(lds_allow, src[r]) ? x : neg_inf<float>();
+                }
+                out[v] = x;
+            }
+            if (q < n_q) *reinterpret_cast<f32x4 *>(&scores_out[(int64_t)q * scores_stride + row]) = out;
+        }
     }
 }
 
