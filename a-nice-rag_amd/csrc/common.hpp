@@ -282,6 +282,7 @@ int dense_tile_group_max(const anrag_index *idx);  // queries K1T holds in LDS a
 int launch_dense_tile(anrag_index *idx, hipStream_t stream, const float *d_queries, int64_t q_stride, int32_t n_queries,
                       const uint32_t *d_allow_bits, float *d_scores_out, int64_t scores_stride);
 bool dense_tile_mfma_has_shape(const anrag_index *idx);  // ... on the matrix cores (dense_tile_mfma.hip)
+int dense_tile_mfma_block_rows(const anrag_index *idx);   // rows per block of that kernel (score rows must hold whole blocks)
 int launch_dense_tile_mfma(anrag_index *idx, hipStream_t stream, const float *d_queries, int64_t q_stride, int32_t n_queries,
                            const uint32_t *d_allow_bits, float *d_scores_out, int64_t scores_stride);
 bool dense_scan_has_shape(const anrag_index *idx);  // a shaped (not the generic) scan kernel serves this dimension

@@ -307,8 +307,9 @@ int launch_dense_tile(anrag_index *idx, hipStream_t st, const float *d_queries, 
                       const uint32_t *d_allow_bits, float *d_scores_out, int64_t scores_stride) {
     {  // rows of 256 / 512 / 768 floats, corpora that fill the chip: the matrix-core form (dense_tile_mfma.hip), same bits
         static const int mfma = [] { const char *e = getenv("ANRAG_TILE_MFMA"); return e ? atoi(e) : 1; }();  // 0: measurements
-        if (mfma && dense_tile_mfma_has_shape(idx) && idx->n_rows >= 32 * (int64_t)idx->n_cus &&
-            scores_stride >= (idx->n_rows + 31) / 32 * 32 && scores_stride % 4 == 0)
+        const int64_t br = dense_tile_mfma_has_shape(idx) ? dense_tile_mfma_block_rows(idx) : 1;
+        if (mfma && dense_tile_mfma_has_shape(idx) && idx->n_rows >= br * (int64_t)idx->n_cus &&
+            scores_stride >= (idx->n_rows + br - 1) / br * br && scores_stride % 4 == 0)
             return launch_dense_tile_mfma(idx, st, d_queries, q_stride, n_queries, d_allow_bits, d_scores_out, scores_stride);
     }
     const int group = dense_tile_group_max(idx);
