@@ -485,6 +485,7 @@ static int dense_single_enqueue(anrag_index *idx, const float *d_query, int32_t 
     return ANRAG_OK;
 }
 
+constexpr int kRankRouteMin = 16;  // queries from which anrag_hybrid_search_batch takes the ranking route
 constexpr int kBm25Group = 16;  // queries per K3 launch of a BM25-only list (anrag_bm25_search_group_device)
 constexpr int kScanGroup = 8;  // queries per scan launch when a call brings several (measured, queries per launch
                                // 1 -> 4 -> 8: 53.6 -> 47.1 -> 45.7 us per query at 100k rows, 64.0 -> 57.9 us at 125k
@@ -1257,6 +1258,33 @@ int anrag_hybrid_search_batch(anrag_index *idx, const float *queries, const int3
                               double w_bm25, double wrrf_k, int32_t top_n, const uint8_t *allow_dense,
                               int32_t n_dense_sources, const uint8_t *allow_bm25, int32_t n_bm25_sources,
                               int64_t *out_id, double *out_score, int32_t *out_count) {
+    // A LIST of 16 queries or more with both legs active and row numbers as document ids is served by the ranking route
+    // (rank_batch.hip): its score tiles read the corpus once per 16 / 32 queries where the pipeline below -- the batch = 1
+    // kernels back to back -- reads it once per query (1M x 768 top-10 lists: 41-45 against 434 us per query); same lists,
+    // same fused scores, same padding.  ANRAG_BATCH_PIPELINE=1 keeps the pipeline (measurements, tests of both).
+    if (idx && queries && term_offsets && out_id && out_score && out_count && n_queries >= kRankRouteMin &&
+        similarity_k > 0 && similarity_k <= ANRAG_FUSED_K_MAX && top_n > 0 && top_n <= 2 * ANRAG_FUSED_K_MAX &&
+        w_dense > 0.0 && w_bm25 > 0.0 && idx->d_emb && idx->d_post_doc && !idx->d_dense_doc && !idx->d_bm25_doc &&
+        idx->dense_doc_base == 0 && idx->bm25_doc_base == 0 && !(allow_dense && !idx->d_dense_src) &&
+        !(allow_bm25 && !idx->d_bm25_src) && !getenv("ANRAG_BATCH_PIPELINE")) {
+        anrag_rank_leg legs[2] = {};
+        legs[0].idx = idx;
+        legs[0].kind = ANRAG_LEG_DENSE;
+        legs[0].queries = queries;
+        legs[0].allow_source = allow_dense;
+        legs[0].n_sources = n_dense_sources;
+        legs[0].weight = w_dense;
+        legs[1].idx = idx;
+        legs[1].kind = ANRAG_LEG_BM25;
+        legs[1].term_ids = term_ids;
+        legs[1].term_offsets = term_offsets;
+        legs[1].allow_source = allow_bm25;
+        legs[1].n_sources = n_bm25_sources;
+        legs[1].weight = w_bm25;
+        const int64_t space = idx->n_rows > idx->n_docs ? idx->n_rows : idx->n_docs;
+        return anrag_rank_batch(legs, 2, n_queries, similarity_k, wrrf_k, top_n, space, out_id, out_score, out_count, nullptr,
+                                nullptr);
+    }
     ANRAG_ENTER(idx);
     ANRAG_REQUIRE(out_id && out_score && out_count && term_offsets, "NULL operand");
     ANRAG_REQUIRE(n_queries >= 0 && n_queries <= (1 << 20), "n_queries %d out of range", n_queries);

@@ -148,3 +148,52 @@ def test_hybrid_batch_equals_single_calls():
         # an empty batch is a no-op
         ids, _, counts = h.hybrid_search_batch(np.zeros((0, d), np.float32), [], 25, 5.0, 1.0, 40.0, 10)
         assert ids.shape == (0, 10) and counts.shape == (0,)
+
+
+def test_hybrid_batch_ranking_route_equals_single_calls_and_the_pipeline():
+    """Row numbers as document ids on both sides and 16 queries or more: `anrag_hybrid_search_batch` takes the ranking route
+    (score tiles + per-list sorts + fusion in LDS, rank_batch.hip).  Row by row it equals `anrag_hybrid_search` -- ids, fused
+    fp64 scores, counts, padding -- with and without a source filter, including a query without terms and one whose terms
+    are outside the vocabulary; and it equals the device pipeline's list form (ANRAG_BATCH_PIPELINE=1) bit for bit."""
+    import os
+
+    from oracle import ref_search
+    from oracle.make_golden import synth_chunks, synth_dense, synth_query
+    from anrag.bm25_index import Bm25Index
+    from anrag.index import Index
+
+    chunks = [c for c in synth_chunks(1300, 191) if c["tokens"]][:1100]
+    n, d = len(chunks), 384
+    e = synth_dense(n, d, 192)
+    e[700] = e[3]  # equal rows: ties inside the dense list
+    bi = Bm25Index([c["tokens"] for c in chunks], k1=1.7, b=0.83, epsilon=0.05)
+    table = {}
+    sid = np.array([table.setdefault(c["source"], len(table)) for c in chunks], dtype=np.uint16)
+    distinct = list(table)
+    rng = np.random.default_rng(16)
+    nq = 41
+    targets = rng.integers(n, size=nq)
+    qs = np.stack([synth_query(e, 900 + i, int(t)) for i, t in enumerate(targets)])
+    terms = [bi.term_ids([str(t) for t in rng.choice(chunks[int(t)]["tokens"], size=int(rng.integers(1, 9)))]) for t in targets]
+    terms[5] = np.zeros(0, np.int32)
+    terms[11] = np.array([-1, -1], np.int32)
+    with Index(0) as h:
+        h.dense_load(e, source_id=sid)
+        h.bm25_load(bi.indptr, bi.post_doc, bi.post_tf, bi.idf, bi.doc_len, bi.avgdl, bi.k1, bi.b, source_id=sid)
+        for sim_k, top_n, flt in ((25, 10, None), (25, 15, "CG,NG"), (64, 128, "NG"), (7, 3, None)):
+            ad = None if flt is None else ref_search.dense_filter_mask(distinct, flt).astype(np.uint8)
+            ab = None if flt is None else ref_search.bm25_filter_mask(distinct, flt).astype(np.uint8)
+            ids, scores, counts = h.hybrid_search_batch(qs, terms, sim_k, 5.0, 1.0, 40.0, top_n, ad, ab)
+            os.environ["ANRAG_BATCH_PIPELINE"] = "1"
+            try:
+                ids_p, scores_p, counts_p = h.hybrid_search_batch(qs, terms, sim_k, 5.0, 1.0, 40.0, top_n, ad, ab)
+            finally:
+                del os.environ["ANRAG_BATCH_PIPELINE"]
+            assert np.array_equal(ids, ids_p) and np.array_equal(counts, counts_p), (sim_k, top_n, flt)
+            assert np.array_equal(scores.view(np.int64), scores_p.view(np.int64)), (sim_k, top_n, flt)
+            for i in range(nq):
+                want_id, want_score = h.hybrid_search(qs[i], terms[i], sim_k, 5.0, 1.0, 40.0, top_n, ad, ab)
+                c = int(counts[i])
+                assert c == len(want_id) and ids[i, :c].tolist() == want_id.tolist(), (i, flt)
+                assert scores[i, :c].tolist() == want_score.tolist()
+                assert (ids[i, c:] == -1).all()
