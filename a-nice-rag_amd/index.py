@@ -69,9 +69,13 @@ def rank_batch(legs: Sequence[dict], n_queries: int, similarity_k: int, wrrf_k: 
             term_lists = leg["term_lists"]
             assert len(term_lists) == n_queries
             offsets = np.zeros(n_queries + 1, dtype=np.int64)
-            np.cumsum([len(t) for t in term_lists], out=offsets[1:])
-            terms = (np.concatenate([np.asarray(t, dtype=np.int32).reshape(-1) for t in term_lists]).astype(np.int32)
-                     if offsets[-1] else np.zeros(1, np.int32))
+            np.cumsum(np.fromiter(map(len, term_lists), np.int64, n_queries), out=offsets[1:])
+            if not offsets[-1]:
+                terms = np.zeros(1, np.int32)
+            elif all(type(t) is np.ndarray and t.dtype == np.int32 and t.ndim == 1 for t in term_lists):
+                terms = np.concatenate(term_lists)  # (what Bm25Index.term_ids returns: no per-list conversion)
+            else:
+                terms = np.concatenate([np.asarray(t, dtype=np.int32).reshape(-1) for t in term_lists]).astype(np.int32)
             terms = np.ascontiguousarray(terms)
             keep += [offsets, terms]
             arr[i].kind = nat.LEG_BM25

@@ -267,11 +267,14 @@ class RetrievalEvaluationSystem:
         info_source = params.get("info_source", "NICE")
         model_weights = params.get("model_weights") or self.config.DEFAULT_MODEL_WEIGHTS.copy()
         flt = params.get("filename_type_filter")
-        try:
-            for q in queries:
-                self._validate_inputs(q.get("query_embeddings"), similarity_k, common_sections_n, info_source)
+        try:  # the shared arguments once, the embeddings of every query (the per-query method raises where the reference raises)
+            self._validate_inputs(queries[0].get("query_embeddings"), similarity_k, common_sections_n, info_source)
         except ValueError:
-            return None  # the per-query method raises where the reference raises
+            return None
+        for q in queries:
+            qe = q.get("query_embeddings")
+            if not qe or not all(isinstance(e, np.ndarray) and e.size for e in qe.values()):
+                return None
         source_enum = InfoSource(info_source.lower())
         embeddings_dict = self.embeddings_data.get(source_enum, {})
         if not embeddings_dict:
@@ -286,10 +289,12 @@ class RetrievalEvaluationSystem:
 
         active = None
         dims = {key: DenseHandle.of(df).dim for key, df in embeddings_dict.items() if df is not None and not df.empty}
+        # (which models can take part is a property of the call, not of a query: `DataFrame.empty` alone costs a microsecond,
+        # and this loop runs thousands of times per evaluation call)
+        usable = [key for key, _, _ in self.config.DENSE_MODELS if key in dims and model_weights.get(key, 0) > 0]
         for q in queries:
-            keys = [key for key, _, _ in self.config.DENSE_MODELS
-                    if embeddings_dict.get(key) is not None and not embeddings_dict[key].empty
-                    and model_weights.get(key, 0) > 0 and key in q["query_embeddings"]]
+            qe = q["query_embeddings"]
+            keys = [key for key in usable if key in qe]
             if active is not None and keys != active:
                 return None  # the queries of one call must share their legs
             active = keys
@@ -408,10 +413,10 @@ class RetrievalEvaluationSystem:
             return ranked()
         keys = None
         token_lists = []
+        usable = [key for key, _, _ in self.config.DENSE_MODELS
+                  if embeddings_dict.get(key) is not None and not embeddings_dict[key].empty and model_weights.get(key, 0) > 0]
         for q in queries:
-            active = [key for key, _, _ in self.config.DENSE_MODELS
-                      if embeddings_dict.get(key) is not None and not embeddings_dict[key].empty
-                      and model_weights.get(key, 0) > 0 and key in q["query_embeddings"]]
+            active = [key for key in usable if key in q["query_embeddings"]]
             if len(active) != 1 or (keys is not None and active[0] != keys):
                 return ranked()
             keys = active[0]
